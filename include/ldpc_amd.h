@@ -1,0 +1,154 @@
+/*
+ * ldpc_amd — C ABI of the MI355X (gfx950) batched LDPC belief-propagation decoder.
+ *
+ * The reference (SebPelay0/ldpc) has no FFI: its decode path is the Python method surface of
+ * `class LDPCEncoder`, one frame per call.  Each entry point below names the reference code it
+ * stands in for.  All pointers are plain C; `*_dev` pointers are device (HIP) addresses on the
+ * current device, everything else is host memory.  No torch types cross this boundary.
+ *
+ * Every function returns LDPC_OK (0) or a positive error code; ldpc_last_error() gives the text
+ * of the calling thread's last failure.  A frame that does not converge is DATA
+ * (converged[f] == 0), never an error — the reference signals it by returning None
+ * (FRAME_ERROR, /root/reference/ldpc.py:15,227).
+ */
+#ifndef LDPC_AMD_H
+#define LDPC_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LDPC_OK 0
+#define LDPC_ERR_ARG 1          /* bad argument (null pointer, bad size, bad enum)            */
+#define LDPC_ERR_HIP 2          /* a HIP runtime call failed; text holds hipGetErrorString      */
+#define LDPC_ERR_UNSUPPORTED 3  /* valid request this build cannot serve (e.g. degree > 64)     */
+#define LDPC_ERR_NO_DEVICE 4    /* no gfx950 device visible                                    */
+
+/* update rules — the five decoders present in the reference */
+#define LDPC_RULE_R0 0 /* /root/reference/ldpc.py:137-227    minSumDecode(codeword, M)            */
+#define LDPC_RULE_R1 1 /* /root/reference/bpsk.py:154-260    minSumDecode(codeword)               */
+#define LDPC_RULE_R2 2 /* /root/reference/bpsk.py:263-387    sumProductDecodeTest(codeword)       */
+#define LDPC_RULE_R3 3 /* /root/reference/channel.py:402-513 sumProductDecodeTest(codeword)       */
+#define LDPC_RULE_R4 4 /* /root/reference/channel.py:260-398 sumProductDecode(codeword) + phi     */
+
+#define LDPC_F32 0
+#define LDPC_F64 1
+
+#define LDPC_KERNEL_AUTO 0 /* circulant kernel when the code has QC structure, else edge-list   */
+#define LDPC_KERNEL_CSR 1  /* generic edge-list kernel                                          */
+#define LDPC_KERNEL_QC 2   /* circulant kernel (error if the handle carries no QC structure)    */
+
+/*
+ * The constants the reference edits in its source, per rule (presets: ldpc_amd/config.py):
+ *   max_iters         ldpc.py:161 (10), bpsk.py:200 (30), bpsk.py:309 (50), channel.py:448 (50),
+ *                     channel.py:306 (40)
+ *   scale             ldpc.py:196 / bpsk.py:233 (0.75), channel.py:474 (0.85)
+ *   clip_tanh_arg     bpsk.py:333 (20); 0 = no clip
+ *   clip_prod         bpsk.py:337 (0.999999999), channel.py:473 (0.99999999)
+ *   clip_post         bpsk.py:370 (30), channel.py:491 (50), channel.py:367 (500); 0 = no clip
+ *   early_exit        1 = the reference's loop: syndrome check at the top of every iteration,
+ *                     none after the last update; iters = numIterations (0..max_iters-1).
+ *                     0 = fixed work: max_iters updates, iters = max_iters, converged = final
+ *                     syndrome (no counterpart in the reference; for throughput runs).
+ *   float_syndrome0   R0: the iteration-0 check is made on the raw LLR floats
+ *                     (ldpc.py:158,165: numpy.dot(H, llr) % 2 == 0).
+ *   num_active_checks R0: rows [0, k) take part in the check-node update (self.m, ldpc.py:30,175);
+ *                     the syndrome always uses every row.  -1 = all.
+ *   num_refresh_vars  R1-R4: variables [0, k) refresh their variable-to-check messages
+ *                     (range(self.n), bpsk.py:244); -1 = all.
+ */
+typedef struct ldpc_decode_config {
+    int32_t rule;
+    int32_t max_iters;
+    int32_t early_exit;
+    int32_t float_syndrome0;
+    int32_t num_active_checks;
+    int32_t num_refresh_vars;
+    double scale;
+    double clip_tanh_arg;
+    double clip_prod;
+    double clip_post;
+} ldpc_decode_config;
+
+typedef struct ldpc_code ldpc_code; /* opaque: compiled parity-check matrix resident on one device */
+
+/* text of the calling thread's most recent error ("" if none) */
+const char *ldpc_last_error(void);
+/* ABI version, bumped on any incompatible change */
+int32_t ldpc_abi_version(void);
+/* number of visible HIP devices; LDPC_ERR_NO_DEVICE if none */
+int32_t ldpc_device_count(int32_t *count);
+
+/*
+ * Compile a parity-check matrix given as a CSR edge list (row_ptr[m+1], col_idx[E], columns
+ * ascending inside each row) into device-resident layouts on the current device.
+ * Replaces the dense `self.H` the reference scans with numpy.where on every check of every
+ * iteration (/root/reference/ldpc.py:176, bpsk.py:214,236) after readMatrix / loadmat
+ * (/root/reference/ldpc.py:360-366, ccsds.py:6-8, channel.py:34).
+ */
+int32_t ldpc_code_create_csr(int32_t m, int32_t n, const int32_t *row_ptr, const int32_t *col_idx,
+                             ldpc_code **out);
+/*
+ * Attach a quasi-cyclic description to a handle: H is an mb x nb array of Z x Z blocks; base edge
+ * e joins check (edge_row[e], z) with variable (edge_col[e], (z + edge_shift[e]) mod Z).
+ * Edges sorted by (row, col, shift).  The description must expand to exactly the CSR matrix the
+ * handle was created from (checked).  No counterpart in the reference (it never exploits the
+ * circulant structure of its matrices).
+ */
+int32_t ldpc_code_attach_qc(ldpc_code *code, int32_t mb, int32_t nb, int32_t Z, int32_t n_base_edges,
+                            const int32_t *edge_row, const int32_t *edge_col,
+                            const int32_t *edge_shift);
+int32_t ldpc_code_destroy(ldpc_code *code);
+/* m, n, number of edges, lifting size (0 if no QC description); any out pointer may be NULL */
+int32_t ldpc_code_info(const ldpc_code *code, int32_t *m, int32_t *n, int64_t *edges, int32_t *Z);
+
+/*
+ * Decode `frames` frames.  Replaces the loop body of LDPCEncoder.minSumDecode /
+ * sumProductDecode(Test) (file:line per rule above) from the point where the channel LLRs exist
+ * (ldpc.py:151) to the return (ldpc.py:170 / 227), for a whole batch per call.
+ *
+ *   llr_dev        [frames, n] row-major channel LLRs, float (llr_dtype LDPC_F32) or double
+ *   compute_dtype  arithmetic type of the message passing (LDPC_F64 reproduces the reference's
+ *                  float64 arithmetic bit for bit under R0/R1)
+ *   hard_dev       [frames, n] uint8 hard decisions (the reference's hardDecisions)
+ *   iters_dev      [frames] int32, the reference's self.numIterations
+ *   converged_dev  [frames] uint8, 0 where the reference would return FRAME_ERROR
+ *   posterior_dev  NULL, or [frames, n] of compute_dtype: the reference's bitNodes at exit
+ *   stream         hipStream_t (NULL = default stream); the call only enqueues work
+ */
+int32_t ldpc_decode_batch(ldpc_code *code, const ldpc_decode_config *cfg, const void *llr_dev,
+                          int32_t llr_dtype, int32_t compute_dtype, int32_t kernel, int64_t frames,
+                          uint8_t *hard_dev, int32_t *iters_dev, uint8_t *converged_dev,
+                          void *posterior_dev, void *stream);
+
+/*
+ * Same, host buffers in and out (allocates device staging, copies, decodes, copies back,
+ * synchronises).  This is what a one-frame-per-call caller such as the reference's drivers
+ * (/root/reference/ldpc.py:392,654, bpsk.py:609,824) binds.
+ */
+int32_t ldpc_decode_batch_host(ldpc_code *code, const ldpc_decode_config *cfg, const void *llr,
+                               int32_t llr_dtype, int32_t compute_dtype, int32_t kernel,
+                               int64_t frames, uint8_t *hard, int32_t *iters, uint8_t *converged,
+                               void *posterior);
+
+/*
+ * Error accounting over a decoded batch (/root/reference/ldpc.py:166-170,210-216 and the FER loop
+ * ldpc.py:644-667): adds into counters_dev[5] (uint64, device):
+ *   [0] frames  [1] frames with converged == 0 (the reference's frame errors)
+ *   [2] frames that converged to a word other than ref  [3] codeword-bit errors (all n bits)
+ *   [4] sum of iters.
+ * ref_dev is [frames, n] uint8 (ref_stride = n) or one shared codeword (ref_stride = 0).
+ */
+int32_t ldpc_count_errors(const uint8_t *hard_dev, const uint8_t *ref_dev, int64_t ref_stride,
+                          const int32_t *iters_dev, const uint8_t *converged_dev, int64_t frames,
+                          int32_t n, uint64_t *counters_dev, void *stream);
+
+/* name of the kernel variant the last ldpc_decode_batch on this thread launched (for tests) */
+const char *ldpc_last_kernel(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LDPC_AMD_H */

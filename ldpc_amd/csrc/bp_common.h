@@ -1,0 +1,67 @@
+// Shared host/device declarations of the decoder library (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ldpc_amd.h"
+
+namespace ldpc {
+
+constexpr int kMaxCheckDegree = 64;  // sign bits of one check are kept in one 64-bit mask
+
+// Edge lists on the device (all int32).
+struct CsrDev {
+    int m, n, E;
+    const int *row_ptr;   // [m+1]
+    const int *col_idx;   // [E] ascending column inside a row
+    const int *col_ptr;   // [n+1]
+    const int *csc_edge;  // [E] per variable, ascending check: position of the edge in CSR order
+};
+
+// Quasi-cyclic description on the device.  Base edges are stored twice: by block row (the order
+// check nodes visit them) and by block column (the order variable nodes sum them, ascending check
+// index).  `slot` is the index of the edge's message vector: message of edge (e, z) lives at
+// slot[e] * Z + z where z is the CHECK's index inside its block row.
+struct QcDev {
+    int mb, nb, Z, Eb;
+    const int *row_ptr;    // [mb+1] into the by-row arrays
+    const int *row_col;    // [Eb] block column
+    const int *row_shift;  // [Eb]
+    const int *col_ptr;    // [nb+1] into the by-column arrays
+    const int *col_slot;   // [Eb] by-row position (message vector) of this edge
+    const int *col_shift;  // [Eb]
+    const int *col_pair;   // [Eb] 1 if the next by-column entry is in the same block row
+    int max_dc, max_dv;
+};
+
+// Rule constants converted to the arithmetic type.
+template <typename T>
+struct Cfg {
+    int rule, max_iters, early_exit, float_syndrome0, num_active_checks, num_refresh_vars;
+    T scale, clip_tanh_arg, clip_prod, clip_post;
+};
+
+struct Launch {
+    const void *llr;
+    int llr_dtype;
+    long long frames;
+    uint8_t *hard;
+    int *iters;
+    uint8_t *converged;
+    void *posterior;
+    hipStream_t stream;
+};
+
+// decode_csr.hip
+hipError_t launch_csr(const CsrDev &code, const ldpc_decode_config &cfg, int compute_dtype,
+                      const Launch &io, int num_cus, void **workspace, size_t *workspace_bytes,
+                      const char **kernel_name);
+// decode_qc.hip
+hipError_t launch_qc(const QcDev &code, const ldpc_decode_config &cfg, int compute_dtype,
+                     const Launch &io, int num_cus, const char **kernel_name, bool *supported);
+// count_errors.hip
+hipError_t launch_count_errors(const uint8_t *hard, const uint8_t *ref, long long ref_stride,
+                               const int *iters, const uint8_t *conv, long long frames, int n,
+                               unsigned long long *counters, hipStream_t stream);
+
+}  // namespace ldpc
