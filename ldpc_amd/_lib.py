@@ -1,0 +1,78 @@
+"""ctypes binding of libldpc_amd.so (the C ABI in include/ldpc_amd.h).
+
+Loading fails loudly: there is no CPU fallback behind this module.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+from .config import CDecodeConfig
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libldpc_amd.so")
+
+LDPC_OK, LDPC_ERR_ARG, LDPC_ERR_HIP, LDPC_ERR_UNSUPPORTED, LDPC_ERR_NO_DEVICE = range(5)
+F32, F64 = 0, 1
+KERNEL_AUTO, KERNEL_CSR, KERNEL_QC = 0, 1, 2
+
+#: every symbol include/ldpc_amd.h declares
+SYMBOLS = ["ldpc_last_error", "ldpc_abi_version", "ldpc_device_count", "ldpc_code_create_csr",
+           "ldpc_code_attach_qc", "ldpc_code_destroy", "ldpc_code_info", "ldpc_decode_batch",
+           "ldpc_decode_batch_host", "ldpc_count_errors", "ldpc_last_kernel"]
+
+
+class LdpcError(RuntimeError):
+    def __init__(self, code: int, text: str):
+        super().__init__(f"ldpc_amd error {code}: {text}")
+        self.code = code
+
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build it with `python -m ldpc_amd.build` "
+                          "(hipcc, --offload-arch=gfx950); there is no CPU fallback")
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, i32, i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
+    lib.ldpc_last_error.restype = ctypes.c_char_p
+    lib.ldpc_last_error.argtypes = []
+    lib.ldpc_last_kernel.restype = ctypes.c_char_p
+    lib.ldpc_last_kernel.argtypes = []
+    lib.ldpc_abi_version.restype = i32
+    lib.ldpc_abi_version.argtypes = []
+    lib.ldpc_device_count.restype = i32
+    lib.ldpc_device_count.argtypes = [ctypes.POINTER(i32)]
+    lib.ldpc_code_create_csr.restype = i32
+    lib.ldpc_code_create_csr.argtypes = [i32, i32, vp, vp, ctypes.POINTER(vp)]
+    lib.ldpc_code_attach_qc.restype = i32
+    lib.ldpc_code_attach_qc.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp]
+    lib.ldpc_code_destroy.restype = i32
+    lib.ldpc_code_destroy.argtypes = [vp]
+    lib.ldpc_code_info.restype = i32
+    lib.ldpc_code_info.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32),
+                                   ctypes.POINTER(i64), ctypes.POINTER(i32)]
+    lib.ldpc_decode_batch.restype = i32
+    lib.ldpc_decode_batch.argtypes = [vp, ctypes.POINTER(CDecodeConfig), vp, i32, i32, i32, i64,
+                                      vp, vp, vp, vp, vp]
+    lib.ldpc_decode_batch_host.restype = i32
+    lib.ldpc_decode_batch_host.argtypes = [vp, ctypes.POINTER(CDecodeConfig), vp, i32, i32, i32,
+                                           i64, vp, vp, vp, vp]
+    lib.ldpc_count_errors.restype = i32
+    lib.ldpc_count_errors.argtypes = [vp, vp, i64, vp, vp, i64, i32, vp, vp]
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    if rc != LDPC_OK:
+        raise LdpcError(rc, load().ldpc_last_error().decode("utf-8", "replace"))
+
+
+def last_kernel() -> str:
+    return load().ldpc_last_kernel().decode()

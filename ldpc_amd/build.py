@@ -1,0 +1,78 @@
+"""In-tree build of libldpc_amd.so (hipcc, gfx950 only).
+
+    python -m ldpc_amd.build [--force] [--jobs N]
+
+hipcc cross-compiles without a GPU; the shared library is written next to this file so that it
+travels with the source tree.  Floating-point contraction is switched off: the float64 kernels
+must perform the reference's operations one by one to reproduce its results bit for bit.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "obj")
+LIB = os.path.join(HERE, "libldpc_amd.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+         "-I", os.path.join(ROOT, "include"), "-I", CSRC]
+
+#: (object name, source, extra flags)
+UNITS = [("ldpc_abi.o", "ldpc_abi.hip", []),
+         ("decode_csr.o", "decode_csr.hip", []),
+         ("count_errors.o", "count_errors.hip", [])]
+UNITS += [(f"decode_qc_r{k}.o", "decode_qc.hip", [f"-DLDPC_QC_RULE={k}"]) for k in range(5)]
+HEADERS = ["bp_common.h", "bp_math.h", os.path.join(ROOT, "include", "ldpc_amd.h")]
+
+
+def _stale(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, jobs: int = 8, verbose: bool = True) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    headers = [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
+    todo = []
+    for obj, src, extra in UNITS:
+        o, s = os.path.join(OBJ, obj), os.path.join(CSRC, src)
+        if force or _stale(o, [s] + headers):
+            todo.append((o, [HIPCC] + FLAGS + extra + ["-c", s, "-o", o]))
+
+    def run(item):
+        o, cmd = item
+        if verbose:
+            print("hipcc", os.path.basename(o), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"{' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
+        if r.stderr.strip() and verbose:
+            print(r.stderr.strip(), file=sys.stderr)
+
+    with ThreadPoolExecutor(max_workers=max(1, jobs)) as pool:
+        list(pool.map(run, todo))
+    objs = [os.path.join(OBJ, obj) for obj, _, _ in UNITS]
+    if force or todo or _stale(LIB, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"{' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
+        if verbose:
+            print("linked", LIB, flush=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--force", action="store_true")
+    ap.add_argument("--jobs", type=int, default=8)
+    a = ap.parse_args()
+    build(a.force, a.jobs)

@@ -19,18 +19,19 @@ struct CsrDev {
 };
 
 // Quasi-cyclic description on the device.  Base edges are stored twice: by block row (the order
-// check nodes visit them) and by block column (the order variable nodes sum them, ascending check
-// index).  `slot` is the index of the edge's message vector: message of edge (e, z) lives at
-// slot[e] * Z + z where z is the CHECK's index inside its block row.
+// check nodes visit them) and by block column (the order variable nodes sum them: ascending block
+// row).  The messages of base edge e (by-row position) form one vector indexed by the CHECK's
+// index z inside its block row.
+//   row_info[e] = block column << 16 | shift
+//   col_info[k] = by-row position of the edge << 16 | pair bit (0x8000) | shift
+// The pair bit says that entry k+1 lies in the same block (a block that is the sum of two
+// circulants); which of the two checks has the smaller index then depends on the lane.
 struct QcDev {
     int mb, nb, Z, Eb;
-    const int *row_ptr;    // [mb+1] into the by-row arrays
-    const int *row_col;    // [Eb] block column
-    const int *row_shift;  // [Eb]
-    const int *col_ptr;    // [nb+1] into the by-column arrays
-    const int *col_slot;   // [Eb] by-row position (message vector) of this edge
-    const int *col_shift;  // [Eb]
-    const int *col_pair;   // [Eb] 1 if the next by-column entry is in the same block row
+    const int *row_ptr;        // [mb+1]
+    const unsigned *row_info;  // [Eb]
+    const int *col_ptr;        // [nb+1]
+    const unsigned *col_info;  // [Eb]
     int max_dc, max_dv;
 };
 
@@ -56,9 +57,13 @@ struct Launch {
 hipError_t launch_csr(const CsrDev &code, const ldpc_decode_config &cfg, int compute_dtype,
                       const Launch &io, int num_cus, void **workspace, size_t *workspace_bytes,
                       const char **kernel_name);
-// decode_qc.hip
-hipError_t launch_qc(const QcDev &code, const ldpc_decode_config &cfg, int compute_dtype,
-                     const Launch &io, int num_cus, const char **kernel_name, bool *supported);
+// decode_qc.hip, one translation unit per rule (-DLDPC_QC_RULE=k)
+#define LDPC_DECL_QC(k)                                                                            \
+    hipError_t launch_qc_rule_##k(const QcDev &code, const ldpc_decode_config &cfg,                \
+                                  int compute_dtype, const Launch &io, int num_cus,                \
+                                  const char **kernel_name, bool *supported);
+LDPC_DECL_QC(0) LDPC_DECL_QC(1) LDPC_DECL_QC(2) LDPC_DECL_QC(3) LDPC_DECL_QC(4)
+#undef LDPC_DECL_QC
 // count_errors.hip
 hipError_t launch_count_errors(const uint8_t *hard, const uint8_t *ref, long long ref_stride,
                                const int *iters, const uint8_t *conv, long long frames, int n,

@@ -1,0 +1,56 @@
+// Error accounting over a decoded batch (ldpc.py:166-170, 210-216; FER loop ldpc.py:644-667).
+//
+// counters[0] += frames, [1] += frames with converged == 0, [2] += frames that converged to a word
+// other than the reference, [3] += codeword-bit errors over all n bits, [4] += sum of iters.
+// One wave per frame at a time; per-workgroup partial sums, then one atomic per counter.
+#include "bp_common.h"
+
+namespace ldpc {
+
+__global__ void __launch_bounds__(256)
+count_errors_kernel(const uint8_t *__restrict__ hard, const uint8_t *__restrict__ ref,
+                    long long ref_stride, const int *__restrict__ iters,
+                    const uint8_t *__restrict__ conv, long long frames, int n,
+                    unsigned long long *__restrict__ counters)
+{
+    __shared__ unsigned long long part[4][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long wave_id = (long long)blockIdx.x * 4 + wave;
+    const long long nwaves = (long long)gridDim.x * 4;
+    unsigned long long nonconv = 0, wrong = 0, biterr = 0, itsum = 0;
+    for (long long f = wave_id; f < frames; f += nwaves) {
+        const uint8_t *h = hard + f * n;
+        const uint8_t *r = ref + f * ref_stride;
+        unsigned e = 0;
+        for (int i = lane; i < n; i += 64) e += h[i] != r[i];
+        for (int off = 32; off > 0; off >>= 1) e += __shfl_down(e, off, 64);
+        if (lane == 0) {
+            const bool c = conv[f] != 0;
+            nonconv += !c;
+            wrong += c && e != 0;
+            biterr += e;
+            itsum += (unsigned long long)iters[f];
+        }
+    }
+    if (lane == 0) { part[wave][0] = nonconv; part[wave][1] = wrong; part[wave][2] = biterr; part[wave][3] = itsum; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        unsigned long long s = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+        if (s) atomicAdd(&counters[1 + threadIdx.x], s);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&counters[0], (unsigned long long)frames);
+}
+
+hipError_t launch_count_errors(const uint8_t *hard, const uint8_t *ref, long long ref_stride,
+                               const int *iters, const uint8_t *conv, long long frames, int n,
+                               unsigned long long *counters, hipStream_t stream)
+{
+    long long blocks = (frames + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(count_errors_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, hard, ref,
+                       ref_stride, iters, conv, frames, n, counters);
+    return hipGetLastError();
+}
+
+}  // namespace ldpc

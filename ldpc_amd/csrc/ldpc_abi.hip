@@ -1,0 +1,339 @@
+// Host side of the C ABI declared in include/ldpc_amd.h: handle management, argument checks,
+// kernel selection.  No decode arithmetic happens on the host; without a HIP device every compute
+// entry point fails with LDPC_ERR_NO_DEVICE / LDPC_ERR_HIP.
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "bp_common.h"
+
+using namespace ldpc;
+
+static thread_local std::string g_err;
+static thread_local const char *g_kernel = "";
+
+static int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail(LDPC_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_));   \
+    } while (0)
+
+struct ldpc_code {
+    int device = 0, num_cus = 0;
+    int m = 0, n = 0, E = 0;
+    int max_dc = 0, max_dv = 0;
+    std::vector<int> row_ptr, col_idx, col_ptr, csc_edge;
+    int *d_ints = nullptr;  // one allocation: row_ptr | col_idx | col_ptr | csc_edge
+    CsrDev csr{};
+    bool has_qc = false;
+    QcDev qc{};
+    int *d_qc = nullptr;    // one allocation: row_ptr | row_info | col_ptr | col_info
+    void *workspace = nullptr;
+    size_t workspace_bytes = 0;
+};
+
+extern "C" const char *ldpc_last_error(void) { return g_err.c_str(); }
+extern "C" const char *ldpc_last_kernel(void) { return g_kernel; }
+extern "C" int32_t ldpc_abi_version(void) { return 1; }
+
+extern "C" int32_t ldpc_device_count(int32_t *count)
+{
+    if (!count) return fail(LDPC_ERR_ARG, "count is NULL");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess || c <= 0) {
+        *count = 0;
+        return fail(LDPC_ERR_NO_DEVICE, "no HIP device visible (%s)", hipGetErrorString(e));
+    }
+    *count = c;
+    return LDPC_OK;
+}
+
+extern "C" int32_t ldpc_code_create_csr(int32_t m, int32_t n, const int32_t *row_ptr,
+                                        const int32_t *col_idx, ldpc_code **out)
+{
+    if (!out) return fail(LDPC_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    if (m <= 0 || n <= 0 || !row_ptr || !col_idx) return fail(LDPC_ERR_ARG, "empty matrix or NULL edge list");
+    if (row_ptr[0] != 0) return fail(LDPC_ERR_ARG, "row_ptr[0] must be 0");
+    for (int j = 0; j < m; ++j)
+        if (row_ptr[j + 1] < row_ptr[j]) return fail(LDPC_ERR_ARG, "row_ptr not monotone at row %d", j);
+    const int E = row_ptr[m];
+    if (E <= 0) return fail(LDPC_ERR_ARG, "matrix has no edges");
+    int max_dc = 0;
+    std::vector<int> deg_v(n, 0);
+    for (int j = 0; j < m; ++j) {
+        max_dc = std::max(max_dc, row_ptr[j + 1] - row_ptr[j]);
+        for (int e = row_ptr[j]; e < row_ptr[j + 1]; ++e) {
+            if (col_idx[e] < 0 || col_idx[e] >= n) return fail(LDPC_ERR_ARG, "column %d out of range in row %d", col_idx[e], j);
+            if (e > row_ptr[j] && col_idx[e] <= col_idx[e - 1])
+                return fail(LDPC_ERR_ARG, "columns of row %d are not strictly ascending", j);
+            deg_v[col_idx[e]]++;
+        }
+    }
+    if (max_dc > kMaxCheckDegree)
+        return fail(LDPC_ERR_UNSUPPORTED, "check degree %d exceeds the supported maximum %d", max_dc, kMaxCheckDegree);
+    int count = 0;
+    if (ldpc_device_count(&count) != LDPC_OK) return LDPC_ERR_NO_DEVICE;
+
+    ldpc_code *c = new ldpc_code;
+    c->m = m; c->n = n; c->E = E; c->max_dc = max_dc;
+    c->row_ptr.assign(row_ptr, row_ptr + m + 1);
+    c->col_idx.assign(col_idx, col_idx + E);
+    c->col_ptr.assign(n + 1, 0);
+    for (int i = 0; i < n; ++i) { c->col_ptr[i + 1] = c->col_ptr[i] + deg_v[i]; c->max_dv = std::max(c->max_dv, deg_v[i]); }
+    c->csc_edge.resize(E);
+    {   // rows are visited in ascending order, so each variable's list comes out in ascending check order
+        std::vector<int> fill(c->col_ptr.begin(), c->col_ptr.end() - 1);
+        for (int j = 0; j < m; ++j)
+            for (int e = row_ptr[j]; e < row_ptr[j + 1]; ++e) c->csc_edge[fill[col_idx[e]]++] = e;
+    }
+    hipError_t e = hipGetDevice(&c->device);
+    hipDeviceProp_t prop;
+    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, c->device);
+    if (e != hipSuccess) { delete c; return fail(LDPC_ERR_HIP, "device query: %s", hipGetErrorString(e)); }
+    c->num_cus = prop.multiProcessorCount;
+    const size_t total = (size_t)(m + 1) + E + (n + 1) + E;
+    e = hipMalloc(reinterpret_cast<void **>(&c->d_ints), total * sizeof(int));
+    if (e != hipSuccess) { delete c; return fail(LDPC_ERR_HIP, "hipMalloc(edge lists): %s", hipGetErrorString(e)); }
+    std::vector<int> host(total);
+    int *p = host.data();
+    std::copy(c->row_ptr.begin(), c->row_ptr.end(), p); p += m + 1;
+    std::copy(c->col_idx.begin(), c->col_idx.end(), p); p += E;
+    std::copy(c->col_ptr.begin(), c->col_ptr.end(), p); p += n + 1;
+    std::copy(c->csc_edge.begin(), c->csc_edge.end(), p);
+    e = hipMemcpy(c->d_ints, host.data(), total * sizeof(int), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(c->d_ints); delete c; return fail(LDPC_ERR_HIP, "hipMemcpy(edge lists): %s", hipGetErrorString(e)); }
+    c->csr.m = m; c->csr.n = n; c->csr.E = E;
+    c->csr.row_ptr = c->d_ints;
+    c->csr.col_idx = c->d_ints + (m + 1);
+    c->csr.col_ptr = c->d_ints + (m + 1) + E;
+    c->csr.csc_edge = c->d_ints + (m + 1) + E + (n + 1);
+    *out = c;
+    return LDPC_OK;
+}
+
+extern "C" int32_t ldpc_code_attach_qc(ldpc_code *c, int32_t mb, int32_t nb, int32_t Z, int32_t Eb,
+                                       const int32_t *er, const int32_t *ec, const int32_t *es)
+{
+    if (!c || !er || !ec || !es) return fail(LDPC_ERR_ARG, "NULL argument");
+    if (mb <= 0 || nb <= 0 || Z <= 0 || Eb <= 0) return fail(LDPC_ERR_ARG, "bad QC dimensions");
+    if ((long long)mb * Z != c->m || (long long)nb * Z != c->n)
+        return fail(LDPC_ERR_ARG, "QC dimensions %dx%d (Z=%d) do not match the %dx%d matrix", mb, nb, Z, c->m, c->n);
+    if (Z > 4095 || Eb > 65535 || nb > 65535)
+        return fail(LDPC_ERR_UNSUPPORTED, "QC description too large for the packed tables");
+    if ((long long)Eb * Z != c->E) return fail(LDPC_ERR_ARG, "QC description has %lld edges, matrix has %d", (long long)Eb * Z, c->E);
+    for (int e = 0; e < Eb; ++e) {
+        if (er[e] < 0 || er[e] >= mb || ec[e] < 0 || ec[e] >= nb || es[e] < 0 || es[e] >= Z)
+            return fail(LDPC_ERR_ARG, "base edge %d out of range", e);
+        if (e > 0) {
+            const bool ordered = er[e] > er[e - 1] || (er[e] == er[e - 1] && (ec[e] > ec[e - 1] || (ec[e] == ec[e - 1] && es[e] > es[e - 1])));
+            if (!ordered) return fail(LDPC_ERR_ARG, "base edges must be sorted by (row, col, shift) without repeats");
+        }
+    }
+    // the description must expand to exactly the matrix of the handle
+    {
+        std::vector<int> cols;
+        for (int br = 0, e = 0; br < mb; ++br) {
+            int e1 = e;
+            while (e1 < Eb && er[e1] == br) ++e1;
+            for (int z = 0; z < Z; ++z) {
+                cols.clear();
+                for (int k = e; k < e1; ++k) cols.push_back(ec[k] * Z + (z + es[k]) % Z);
+                std::sort(cols.begin(), cols.end());
+                const int j = br * Z + z;
+                if ((int)cols.size() != c->row_ptr[j + 1] - c->row_ptr[j] ||
+                    !std::equal(cols.begin(), cols.end(), c->col_idx.begin() + c->row_ptr[j]))
+                    return fail(LDPC_ERR_ARG, "QC description does not expand to the matrix (check row %d)", j);
+            }
+            e = e1;
+        }
+    }
+    std::vector<int> row_ptr(mb + 1, 0), col_ptr(nb + 1, 0);
+    std::vector<unsigned> row_info(Eb), col_info(Eb);
+    for (int e = 0; e < Eb; ++e) { row_ptr[er[e] + 1]++; col_ptr[ec[e] + 1]++; }
+    for (int i = 0; i < mb; ++i) row_ptr[i + 1] += row_ptr[i];
+    for (int i = 0; i < nb; ++i) col_ptr[i + 1] += col_ptr[i];
+    int max_dc = 0, max_dv = 0;
+    for (int i = 0; i < mb; ++i) max_dc = std::max(max_dc, row_ptr[i + 1] - row_ptr[i]);
+    for (int i = 0; i < nb; ++i) max_dv = std::max(max_dv, col_ptr[i + 1] - col_ptr[i]);
+    for (int e = 0; e < Eb; ++e) row_info[e] = ((unsigned)ec[e] << 16) | (unsigned)es[e];
+    {
+        std::vector<int> fill(col_ptr.begin(), col_ptr.end() - 1);
+        std::vector<int> last_row(nb, -1), run(nb, 0);
+        for (int e = 0; e < Eb; ++e) {  // ascending block row inside each column
+            const int bc = ec[e], k = fill[bc]++;
+            col_info[k] = ((unsigned)e << 16) | (unsigned)es[e];
+            if (last_row[bc] == er[e]) {
+                if (++run[bc] > 2)
+                    return fail(LDPC_ERR_UNSUPPORTED, "block (%d,%d) is the sum of more than two circulants", er[e], bc);
+                col_info[k - 1] |= 0x8000u;
+            } else {
+                run[bc] = 1;
+            }
+            last_row[bc] = er[e];
+        }
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t total = (size_t)(mb + 1) + Eb + (nb + 1) + Eb;
+    std::vector<int> host(total);
+    int *p = host.data();
+    std::copy(row_ptr.begin(), row_ptr.end(), p); p += mb + 1;
+    std::memcpy(p, row_info.data(), Eb * sizeof(int)); p += Eb;
+    std::copy(col_ptr.begin(), col_ptr.end(), p); p += nb + 1;
+    std::memcpy(p, col_info.data(), Eb * sizeof(int));
+    if (c->d_qc) { (void)hipFree(c->d_qc); c->d_qc = nullptr; c->has_qc = false; }
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_qc), total * sizeof(int)));
+    HIP_TRY(hipMemcpy(c->d_qc, host.data(), total * sizeof(int), hipMemcpyHostToDevice));
+    c->qc.mb = mb; c->qc.nb = nb; c->qc.Z = Z; c->qc.Eb = Eb;
+    c->qc.row_ptr = c->d_qc;
+    c->qc.row_info = reinterpret_cast<const unsigned *>(c->d_qc + (mb + 1));
+    c->qc.col_ptr = c->d_qc + (mb + 1) + Eb;
+    c->qc.col_info = reinterpret_cast<const unsigned *>(c->d_qc + (mb + 1) + Eb + (nb + 1));
+    c->qc.max_dc = max_dc; c->qc.max_dv = max_dv;
+    c->has_qc = true;
+    return LDPC_OK;
+}
+
+extern "C" int32_t ldpc_code_destroy(ldpc_code *c)
+{
+    if (!c) return LDPC_OK;
+    if (c->d_ints) (void)hipFree(c->d_ints);
+    if (c->d_qc) (void)hipFree(c->d_qc);
+    if (c->workspace) (void)hipFree(c->workspace);
+    delete c;
+    return LDPC_OK;
+}
+
+extern "C" int32_t ldpc_code_info(const ldpc_code *c, int32_t *m, int32_t *n, int64_t *edges, int32_t *Z)
+{
+    if (!c) return fail(LDPC_ERR_ARG, "code is NULL");
+    if (m) *m = c->m;
+    if (n) *n = c->n;
+    if (edges) *edges = c->E;
+    if (Z) *Z = c->has_qc ? c->qc.Z : 0;
+    return LDPC_OK;
+}
+
+static int check_cfg(const ldpc_decode_config *cfg)
+{
+    if (!cfg) return fail(LDPC_ERR_ARG, "cfg is NULL");
+    if (cfg->rule < 0 || cfg->rule > 4) return fail(LDPC_ERR_ARG, "rule %d is not one of R0..R4", cfg->rule);
+    if (cfg->max_iters < 1 || cfg->max_iters > 100000) return fail(LDPC_ERR_ARG, "max_iters %d out of range", cfg->max_iters);
+    if ((cfg->rule == 2 || cfg->rule == 3) && !(cfg->clip_prod > 0.0 && cfg->clip_prod <= 1.0))
+        return fail(LDPC_ERR_ARG, "clip_prod must lie in (0, 1] for the tanh rules");
+    return LDPC_OK;
+}
+
+extern "C" int32_t ldpc_decode_batch(ldpc_code *c, const ldpc_decode_config *cfg, const void *llr_dev,
+                                     int32_t llr_dtype, int32_t compute_dtype, int32_t kernel,
+                                     int64_t frames, uint8_t *hard_dev, int32_t *iters_dev,
+                                     uint8_t *converged_dev, void *posterior_dev, void *stream)
+{
+    if (!c) return fail(LDPC_ERR_ARG, "code is NULL");
+    if (int rc = check_cfg(cfg)) return rc;
+    if (frames < 0) return fail(LDPC_ERR_ARG, "negative frame count");
+    if ((llr_dtype != LDPC_F32 && llr_dtype != LDPC_F64) || (compute_dtype != LDPC_F32 && compute_dtype != LDPC_F64))
+        return fail(LDPC_ERR_ARG, "dtype must be LDPC_F32 or LDPC_F64");
+    if (kernel < LDPC_KERNEL_AUTO || kernel > LDPC_KERNEL_QC) return fail(LDPC_ERR_ARG, "unknown kernel selector %d", kernel);
+    if (frames == 0) { g_kernel = "none"; return LDPC_OK; }
+    if (!llr_dev || !hard_dev || !iters_dev || !converged_dev) return fail(LDPC_ERR_ARG, "NULL buffer");
+    HIP_TRY(hipSetDevice(c->device));
+
+    Launch io{llr_dev, llr_dtype, (long long)frames, hard_dev, iters_dev, converged_dev, posterior_dev,
+              reinterpret_cast<hipStream_t>(stream)};
+    // the loop-bound quirks exist only in the edge-list kernel
+    const bool quirks = (cfg->rule == 0 && cfg->num_active_checks >= 0 && cfg->num_active_checks < c->m) ||
+                        (cfg->rule != 0 && cfg->num_refresh_vars >= 0 && cfg->num_refresh_vars < c->n);
+    if (kernel == LDPC_KERNEL_QC && !c->has_qc) return fail(LDPC_ERR_ARG, "no QC description attached to this code");
+    if (kernel == LDPC_KERNEL_QC && quirks)
+        return fail(LDPC_ERR_UNSUPPORTED, "num_active_checks / num_refresh_vars need the edge-list kernel");
+    if (kernel != LDPC_KERNEL_CSR && c->has_qc && !quirks) {
+        bool supported = false;
+        hipError_t e = hipSuccess;
+        switch (cfg->rule) {
+            case 0: e = launch_qc_rule_0(c->qc, *cfg, compute_dtype, io, c->num_cus, &g_kernel, &supported); break;
+            case 1: e = launch_qc_rule_1(c->qc, *cfg, compute_dtype, io, c->num_cus, &g_kernel, &supported); break;
+            case 2: e = launch_qc_rule_2(c->qc, *cfg, compute_dtype, io, c->num_cus, &g_kernel, &supported); break;
+            case 3: e = launch_qc_rule_3(c->qc, *cfg, compute_dtype, io, c->num_cus, &g_kernel, &supported); break;
+            case 4: e = launch_qc_rule_4(c->qc, *cfg, compute_dtype, io, c->num_cus, &g_kernel, &supported); break;
+        }
+        if (e != hipSuccess) return fail(LDPC_ERR_HIP, "circulant kernel launch: %s", hipGetErrorString(e));
+        if (supported) return LDPC_OK;
+        if (kernel == LDPC_KERNEL_QC)
+            return fail(LDPC_ERR_UNSUPPORTED, "circulant kernel cannot serve this code/dtype (LDS footprint or degree)");
+    }
+    hipError_t e = launch_csr(c->csr, *cfg, compute_dtype, io, c->num_cus, &c->workspace, &c->workspace_bytes, &g_kernel);
+    if (e != hipSuccess) return fail(LDPC_ERR_HIP, "edge-list kernel launch: %s", hipGetErrorString(e));
+    return LDPC_OK;
+}
+
+extern "C" int32_t ldpc_decode_batch_host(ldpc_code *c, const ldpc_decode_config *cfg, const void *llr,
+                                          int32_t llr_dtype, int32_t compute_dtype, int32_t kernel,
+                                          int64_t frames, uint8_t *hard, int32_t *iters,
+                                          uint8_t *converged, void *posterior)
+{
+    if (!c) return fail(LDPC_ERR_ARG, "code is NULL");
+    if (frames < 0) return fail(LDPC_ERR_ARG, "negative frame count");
+    if (frames == 0) return ldpc_decode_batch(c, cfg, nullptr, llr_dtype, compute_dtype, kernel, 0, nullptr, nullptr, nullptr, nullptr, nullptr);
+    if (!llr || !hard || !iters || !converged) return fail(LDPC_ERR_ARG, "NULL buffer");
+    if ((llr_dtype != LDPC_F32 && llr_dtype != LDPC_F64) || (compute_dtype != LDPC_F32 && compute_dtype != LDPC_F64))
+        return fail(LDPC_ERR_ARG, "dtype must be LDPC_F32 or LDPC_F64");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t cells = (size_t)frames * c->n;
+    const size_t llr_b = cells * (llr_dtype == LDPC_F64 ? 8 : 4);
+    const size_t post_b = posterior ? cells * (compute_dtype == LDPC_F64 ? 8 : 4) : 0;
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t total = up(llr_b) + up(cells) + up((size_t)frames * 4) + up((size_t)frames) + up(post_b);
+    char *d = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d), total));
+    char *d_llr = d, *d_hard = d_llr + up(llr_b), *d_it = d_hard + up(cells),
+         *d_cv = d_it + up((size_t)frames * 4), *d_post = d_cv + up((size_t)frames);
+    int rc = LDPC_OK;
+    hipError_t e = hipMemcpy(d_llr, llr, llr_b, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        rc = ldpc_decode_batch(c, cfg, d_llr, llr_dtype, compute_dtype, kernel, frames,
+                               reinterpret_cast<uint8_t *>(d_hard), reinterpret_cast<int32_t *>(d_it),
+                               reinterpret_cast<uint8_t *>(d_cv), posterior ? d_post : nullptr, nullptr);
+        if (rc == LDPC_OK) {
+            e = hipDeviceSynchronize();
+            if (e == hipSuccess) e = hipMemcpy(hard, d_hard, cells, hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipMemcpy(iters, d_it, (size_t)frames * 4, hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipMemcpy(converged, d_cv, (size_t)frames, hipMemcpyDeviceToHost);
+            if (e == hipSuccess && posterior) e = hipMemcpy(posterior, d_post, post_b, hipMemcpyDeviceToHost);
+        }
+    }
+    (void)hipFree(d);
+    if (rc != LDPC_OK) return rc;
+    if (e != hipSuccess) return fail(LDPC_ERR_HIP, "host decode: %s", hipGetErrorString(e));
+    return LDPC_OK;
+}
+
+extern "C" int32_t ldpc_count_errors(const uint8_t *hard_dev, const uint8_t *ref_dev, int64_t ref_stride,
+                                     const int32_t *iters_dev, const uint8_t *converged_dev,
+                                     int64_t frames, int32_t n, uint64_t *counters_dev, void *stream)
+{
+    if (frames < 0 || n <= 0) return fail(LDPC_ERR_ARG, "bad frame count or n");
+    if (frames == 0) return LDPC_OK;
+    if (!hard_dev || !ref_dev || !iters_dev || !converged_dev || !counters_dev) return fail(LDPC_ERR_ARG, "NULL buffer");
+    if (ref_stride != 0 && ref_stride != n) return fail(LDPC_ERR_ARG, "ref_stride must be 0 or n");
+    hipError_t e = launch_count_errors(hard_dev, ref_dev, ref_stride, iters_dev, converged_dev, frames, n,
+                                       reinterpret_cast<unsigned long long *>(counters_dev),
+                                       reinterpret_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(LDPC_ERR_HIP, "count_errors launch: %s", hipGetErrorString(e));
+    return LDPC_OK;
+}

@@ -1,0 +1,139 @@
+"""Parity of the HIP decoders (through the C ABI) with the golden vectors and the CPU oracle.
+
+float64 arithmetic: hard decisions, iteration counts and convergence flags must be identical to
+the reference's; posteriors identical to the last bit for the min-sum rules R0/R1 (same operations
+in the same order) and within 1e-4 relative for the sum-product rules (device libm vs numpy).
+float32 arithmetic (frames whose LLRs are exactly representable in float32): same convergence
+flags and iteration counts; on frames that converge the same hard decisions and posteriors within
+1e-4 relative (the tolerance the task states for message LLRs).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import golden_files, load_golden, rule_config
+from ldpc_amd import codes
+from oracle import bp_oracle
+
+pytestmark = pytest.mark.gpu
+
+ALL = golden_files()
+KERNELS = {"csr": 1, "qc": 2}
+
+_decoders = {}
+
+
+def decoder_for(name):
+    from ldpc_amd.decoder import Decoder
+    if name not in _decoders:
+        _decoders[name] = Decoder(codes.load_packaged(name))
+    return _decoders[name]
+
+
+def _ids(files):
+    return [os.path.basename(f)[:-4] for f in files]
+
+
+def _rel_err(a, b):
+    scale = np.maximum(np.abs(b), 1.0)
+    return float(np.max(np.abs(a - b) / scale)) if a.size else 0.0
+
+
+@pytest.mark.parametrize("kernel", ["csr", "qc"])
+@pytest.mark.parametrize("path", ALL, ids=_ids(ALL))
+def test_f64_matches_reference(path, kernel):
+    g = load_golden(path)
+    cfg = rule_config(g["rule"])
+    dec = decoder_for(g["code"])
+    L = bp_oracle.llr_from_samples(g["y"].astype(np.float64), g["snr_attr"], cfg.rule)
+    res = dec.decode(L, cfg, compute_dtype=np.float64, want_posterior=True, kernel=KERNELS[kernel])
+    assert res.kernel.startswith(kernel), res.kernel
+    assert np.array_equal(res.converged, g["converged"])
+    assert np.array_equal(res.iters, g["iters"])
+    assert np.array_equal(res.hard, g["hard"].astype(np.uint8))
+    if cfg.rule <= 1:
+        assert np.array_equal(res.posterior, g["posterior"])
+    else:
+        assert _rel_err(res.posterior, g["posterior"]) <= 1e-4
+    # the reference's return value: BER over all n bits on success
+    ber = (res.hard != g["codeword"]).mean(axis=1)
+    ok = g["converged"]
+    assert np.array_equal(ber[ok], g["ret"][ok])
+
+
+@pytest.mark.parametrize("kernel", ["csr", "qc"])
+@pytest.mark.parametrize("path", ALL, ids=_ids(ALL))
+def test_f32_matches_reference(path, kernel):
+    g = load_golden(path)
+    cfg = rule_config(g["rule"])
+    dec = decoder_for(g["code"])
+    exact = g["snr_attr"] == 0.0      # LLR = 4*y (2*y for R2): representable in float32
+    L = bp_oracle.llr_from_samples(g["y"].astype(np.float64), g["snr_attr"], cfg.rule)[exact]
+    L32 = L.astype(np.float32)
+    if cfg.rule != 1:                 # R1's punctured-prefix value 1e-9 is not a float32 value
+        assert np.array_equal(L32.astype(np.float64), L)
+    res = dec.decode(L32, cfg, compute_dtype=np.float32, want_posterior=True, kernel=KERNELS[kernel])
+    assert res.kernel.startswith(kernel), res.kernel
+    conv, iters = g["converged"][exact], g["iters"][exact]
+    hard, post = g["hard"][exact].astype(np.uint8), g["posterior"][exact]
+    if cfg.rule <= 1:
+        assert np.array_equal(res.converged, conv)
+        assert np.array_equal(res.iters, iters)
+        # frames that converge: same word, posteriors within the stated 1e-4.  Frames that do not
+        # converge wander for the whole iteration budget and float32 rounding is amplified along
+        # the way, so only their flag and iteration count are comparable.
+        assert np.array_equal(res.hard[conv], hard[conv])
+        assert _rel_err(res.posterior[conv].astype(np.float64), post[conv]) <= 1e-4
+    else:
+        # float32 saturates the tanh product one ulp below 1 (|message| <= 17.3 instead of 21.4 /
+        # 19.1), so sum-product trajectories are close, not identical: converged frames must
+        # decode to the same word; iteration counts may differ by a step
+        same = res.converged & conv
+        assert same.sum() >= 0.9 * conv.sum()
+        assert np.array_equal(res.hard[same], hard[same])
+        assert np.abs(res.iters[same] - iters[same]).max(initial=0) <= 2
+
+
+@pytest.mark.parametrize("rule", ["R0", "R1"])
+@pytest.mark.parametrize("name", ["ccsds512", "wifi648", "nr_bg2_z40", "nr_bg2_z40_r1400"])
+def test_f64_batch_matches_c_oracle(rule, name, c_oracle):
+    """A few thousand random frames around the waterfall, both kernels, bit for bit."""
+    from ldpc_amd import config
+    cfg = config.PRESETS[rule]
+    code = codes.load_packaged(name)
+    G = codes.load_packaged_generator(name)
+    rng = np.random.default_rng([11, cfg.rule, len(name)])
+    B = 2048 if code.n <= 648 else 512
+    cw = codes.encode(G, rng.integers(0, 2, size=(B, G.shape[0])))
+    snr = {"ccsds512": 1.0, "wifi648": -1.0, "nr_bg2_z40": -6.0, "nr_bg2_z40_r1400": -5.0}[name]
+    sigma2 = 1.0 / (2.0 * 10 ** (snr / 10))
+    x = 2.0 * cw - 1.0 if cfg.plus_is_bit == 1 else 1.0 - 2.0 * cw
+    y = x + np.sqrt(sigma2) * rng.standard_normal(x.shape)
+    L = bp_oracle.llr_from_samples(y, snr, cfg.rule)
+    eh, ei, ec, ep = c_oracle.c_decode(code, cfg, L)
+    dec = decoder_for(name)
+    for kernel in ("csr", "qc"):
+        res = dec.decode(L, cfg, compute_dtype=np.float64, want_posterior=True, kernel=KERNELS[kernel])
+        assert np.array_equal(res.converged, ec), kernel
+        assert np.array_equal(res.iters, ei), kernel
+        assert np.array_equal(res.hard, eh), kernel
+        assert np.array_equal(res.posterior, ep), kernel
+    assert 0 < ec.sum() < B or rule == "R0"  # the batch straddles the waterfall
+
+
+def test_fixed_iterations_mode(c_oracle):
+    from ldpc_amd import config
+    code = codes.load_packaged("ccsds512")
+    dec = decoder_for("ccsds512")
+    rng = np.random.default_rng(5)
+    L = 4.0 * (-1.0 + 0.8 * rng.standard_normal((256, code.n)))
+    for rule in ("R0", "R1"):
+        cfg = config.PRESETS[rule].with_(max_iters=10, early_exit=False)
+        eh, ei, ec, ep = c_oracle.c_decode(code, cfg, L)
+        for kernel in ("csr", "qc"):
+            res = dec.decode(L, cfg, want_posterior=True, kernel=KERNELS[kernel])
+            assert np.array_equal(res.iters, ei) and (res.iters == 10).all()
+            assert np.array_equal(res.converged, ec)
+            assert np.array_equal(res.hard, eh)
+            assert np.array_equal(res.posterior, ep)
