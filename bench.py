@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""Throughput of the batched LDPC decoder on MI355X: decoded info Gbit/s.
+
+    python bench.py --gpus 1 --steps 10 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One step = one decode launch over a batch of synthetic frames resident in HBM.  The default
+workload is the CCSDS (512,256) code, 2^20 frames per launch and per GPU, the reference's own
+ldpc.py decoder (rule R0, at most 10 iterations with a syndrome check at the top of each), float64
+arithmetic (bit-exact with the reference), at an SNR low enough that practically every frame uses
+the whole iteration budget — so "10 BP iterations" are really executed.  Frames are independent:
+every rank decodes its own batch (weak scaling) and the ranks meet only in the all-reduce of the
+error counters.
+
+Rank 0 prints one JSON line.  Beside the headline value it carries
+  roofline      algorithmic HBM bytes per launch / measured kernel time, against 8 TB/s
+  lds_roofline  algorithmic LDS bytes of the executed iterations against the nominal LDS rate
+  cpu_baseline  the CPU restatement (oracle/bp_oracle.c, OpenMP) timed on a bounded sample of the
+                same LLRs on this host, which doubles as a parity check of that sample
+  other         secondary workloads (early exit at an operating SNR, float32, rule R1), N=1 only
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E peak
+LDS_PEAK_GBS = 128 * 256 * 2.4   # 128 B/clk/CU x 256 CUs x 2.4 GHz = 78.6 TB/s (nominal)
+
+
+def lds_bytes_per_frame_iter(code, rule, itemsize):
+    """Algorithmic LDS traffic of one flooding iteration of one frame."""
+    E, n = code.num_edges, code.n
+    per4 = (12 * E + 4 * n) if rule == 0 else 16 * E
+    return per4 * itemsize // 4
+
+
+def timed_steps(fn, steps, warmup, torch, dist, world):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(steps):
+        fn()
+    ev1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)
+    if world > 1:
+        t = torch.tensor([wall, dev_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall, dev_ms = float(t[0]), float(t[1])
+    return wall, dev_ms
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=1 << 20, help="frames per launch per GPU")
+    ap.add_argument("--code", default="ccsds512")
+    ap.add_argument("--rule", default="R0")
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--snr", type=float, default=-3.0, help="Es/N0 in dB of the synthetic channel")
+    ap.add_argument("--max-iters", type=int, default=10)
+    ap.add_argument("--kernel", type=int, default=0)
+    ap.add_argument("--cpu-sample", type=int, default=0, help="frames of the CPU baseline (0 = auto)")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-other", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the decoder has no CPU path")
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    device = torch.device("cuda", local)
+
+    from ldpc_amd import codes, config, sweep
+    from ldpc_amd.decoder import Decoder
+
+    code = codes.load_packaged(args.code)
+    G = codes.load_packaged_generator(args.code)
+    k_info = G.shape[0]
+    cfg = config.PRESETS[args.rule].with_(max_iters=args.max_iters)
+    compute = np.float64 if args.dtype == "f64" else np.float32
+    dec = Decoder(code)
+    batch = sweep.make_batch(code, G, args.frames, args.snr, cfg, seed=[7, rank], device=device)
+    kernel_name = [""]
+
+    def step():
+        kernel_name[0] = sweep.decode_batch(dec, batch, cfg, compute_dtype=compute, kernel=args.kernel)
+
+    wall, dev_ms = timed_steps(step, args.steps, args.warmup, torch, dist, world)
+    frames_total = args.frames * world * args.steps
+    value = frames_total * k_info / wall / 1e9
+
+    # error counters of the last step, summed over ranks: the one collective of the path
+    batch.counters.zero_()
+    sweep.count_errors(dec, batch)
+    sweep.allreduce_counters(batch.counters)
+    torch.cuda.synchronize()
+    stats = sweep.summarize(batch.counters.cpu().numpy(), code.n)
+
+    kernel_ms = dev_ms / args.steps
+    hbm_bytes = (5 * code.n + 5) * args.frames                  # f32 LLR in, u8 hard + i32 + u8 out
+    executed = stats["iterations"] + stats["not_converged"]     # failures ran max_iters, report max-1
+    lds_bytes = lds_bytes_per_frame_iter(code, cfg.rule, 8 if args.dtype == "f64" else 4) * executed / world
+    roofline = {"bound": "hbm", "achieved": hbm_bytes / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "traffic": None, "kernel": kernel_name[0], "kernel_ms": kernel_ms,
+                "bytes_per_frame": 5 * code.n + 5}
+    roofline["frac"] = roofline["achieved"] / roofline["peak"]
+    lds = {"bound": "lds", "achieved": lds_bytes / (kernel_ms * 1e-3) / 1e9, "peak": LDS_PEAK_GBS,
+           "unit": "GB/s", "bytes_per_frame_iter": lds_bytes_per_frame_iter(code, cfg.rule, 8 if args.dtype == "f64" else 4)}
+    lds["frac"] = lds["achieved"] / lds["peak"]
+
+    out = {
+        "metric": "decoded info Gbit/s", "value": value, "unit": "Gbit/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+        "data": "synthetic",
+        "config": {"workload": f"{args.code} (n={code.n}, k={k_info}) x {args.frames} frames/launch/GPU, "
+                               f"rule {args.rule} ({'ldpc.py' if args.rule == 'R0' else 'bpsk.py'} decoder), "
+                               f"max {args.max_iters} iterations, syndrome check per iteration, Es/N0 {args.snr} dB",
+                   "code": args.code, "frames_per_launch_per_gpu": args.frames, "rule": args.rule,
+                   "max_iters": args.max_iters, "early_exit": True, "es_n0_db": args.snr,
+                   "llr_dtype": "f32", "kernel": kernel_name[0], "sharding": f"frames x{world}"},
+        "mean_iters": stats["mean_iters"], "fer": stats["fer"], "ber": stats["ber"],
+        "counters": {k: stats[k] for k in sweep.COUNTER_NAMES},
+        "roofline": roofline, "lds_roofline": lds,
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(code, cfg, batch, k_info, args)
+    if rank == 0 and world == 1 and not args.no_other:
+        out["other"] = other_workloads(code, G, dec, args, torch, dist, device)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+def cpu_baseline(code, cfg, batch, k_info, args):
+    """CPU restatement on a bounded sample of the same LLRs, all host threads; also checks that
+    the GPU's results for that sample are identical."""
+    from oracle import bp_oracle
+    bp_oracle.build_c_oracle()
+    threads = min(bp_oracle.c_max_threads(), len(os.sched_getaffinity(0)), 64)
+    probe = 64 * threads
+    L = batch.llr[:probe].cpu().numpy().astype(np.float64)
+    t0 = time.perf_counter()
+    bp_oracle.c_decode(code, cfg, L, nthreads=threads, want_posterior=False)
+    rate = probe / max(time.perf_counter() - t0, 1e-6)
+    sample = args.cpu_sample or int(min(batch.llr.shape[0], max(probe, rate * 15.0)))
+    L = batch.llr[:sample].cpu().numpy().astype(np.float64)
+    t0 = time.perf_counter()
+    hard, iters, conv, _ = bp_oracle.c_decode(code, cfg, L, nthreads=threads, want_posterior=False)
+    dt = time.perf_counter() - t0
+    same = (np.array_equal(hard, batch.hard[:sample].cpu().numpy())
+            and np.array_equal(iters, batch.iters[:sample].cpu().numpy())
+            and np.array_equal(conv, batch.converged[:sample].cpu().numpy().astype(bool)))
+    return {"value": sample * k_info / dt / 1e9, "unit": "Gbit/s", "cores": threads, "kind": "port",
+            "sample": f"first {sample} frames of the same LLR batch, float64, oracle/bp_oracle.c with "
+                      f"{threads} OpenMP threads, {dt:.1f} s",
+            "gpu_results_identical_on_sample": bool(same) if args.dtype == "f64" else None}
+
+
+def other_workloads(code, G, dec, args, torch, dist, device):
+    from ldpc_amd import config, sweep
+    res = {}
+    frames = min(args.frames, 1 << 19)
+    for label, rule, dtype, snr, early in [
+        ("R0_f64_es_n0_1dB", "R0", "f64", 1.0, True),
+        ("R0_f32_worst_case", "R0", "f32", args.snr, True),
+        ("R1_f64_worst_case", "R1", "f64", args.snr, True),
+        ("R1_f64_es_n0_1dB", "R1", "f64", 1.0, True),
+        ("R1_f32_worst_case", "R1", "f32", args.snr, True),
+        ("R0_f64_fixed_10", "R0", "f64", args.snr, False),
+    ]:
+        cfg = config.PRESETS[rule].with_(max_iters=args.max_iters, early_exit=early)
+        batch = sweep.make_batch(code, G, frames, snr, cfg, seed=[8, len(label)], device=device)
+        compute = np.float64 if dtype == "f64" else np.float32
+        wall, dev_ms = timed_steps(lambda: sweep.decode_batch(dec, batch, cfg, compute_dtype=compute),
+                                   3, 1, torch, dist, 1)
+        sweep.count_errors(dec, batch)
+        torch.cuda.synchronize()
+        st = sweep.summarize(batch.counters.cpu().numpy(), code.n)
+        res[label] = {"gbit_s": frames * 3 * G.shape[0] / wall / 1e9, "mean_iters": st["mean_iters"],
+                      "fer": st["fer"], "ber": st["ber"], "frames": frames}
+        del batch
+    return res
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,55 @@
+"""LLR producers in front of the decode path (host side, numpy).
+
+The reference forms channel LLRs inside each decode method from BPSK samples and ``self.SNR``;
+the formulas differ per method and two opposite BPSK polarities are in use:
+
+* ``addNoiseBPSK`` (/root/reference/ldpc.py:241-266): x = 2b - 1, sigma^2 = 1 / (2 * 10^(SNR/10)),
+  i.e. bit 1 is sent as +1 — the polarity R0's hard decision assumes (ldpc.py:198-201);
+* ``pyldpc.encode`` behind ``LDPCEncoder.encode`` (/root/reference/ldpc.py:52): x = (-1)^b, bit 0 is
+  sent as +1 — the polarity R1-R4 assume (bpsk.py:240-243).  That package is not part of the
+  reference tree; only the polarity matters here and the noise level is taken as in
+  ``addNoiseBPSK``.
+
+"SNR" is Es/N0-like everywhere in the reference: no code-rate term.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .config import DecodeConfig, RULE_R1, RULE_R2, RULE_R3, RULE_R4
+
+#: number of leading code bits whose LLR the reference overwrites (bpsk.py:163, channel.py:270,412)
+PUNCTURE_PREFIX = 80
+
+
+def noise_variance(snr_db) -> np.ndarray:
+    """sigma^2 = 1 / (2 * 10^(SNR/10))  (ldpc.py:143)."""
+    return 1 / (2 * (10 ** (np.asarray(snr_db, dtype=np.float64) / 10)))
+
+
+def bpsk_awgn(codewords: np.ndarray, snr_db: float, plus_is_bit: int, rng: np.random.Generator) -> np.ndarray:
+    """BPSK symbols plus white Gaussian noise of variance ``noise_variance(snr_db)``."""
+    c = np.asarray(codewords, dtype=np.float64)
+    x = 2.0 * c - 1.0 if plus_is_bit == 1 else 1.0 - 2.0 * c
+    return x + np.sqrt(noise_variance(snr_db)) * rng.standard_normal(c.shape)
+
+
+def llr_from_samples(y: np.ndarray, snr_db, cfg: DecodeConfig, compat_prefix: bool = True) -> np.ndarray:
+    """Channel LLRs as the reference's decode method for ``cfg.rule`` forms them.
+
+    R0: 2y/sigma^2 (ldpc.py:143-144).  R1: the same with the first 80 set to 1e-9 (bpsk.py:161-167).
+    R2: y/sigma^2, no factor 2 and no overwritten prefix (bpsk.py:271-277).  R3/R4: 2y/sigma^2 with
+    the first 80 set to 0.0 (channel.py:410-416, 268-274).  ``compat_prefix=False`` leaves the
+    prefix alone (for codes that are not punctured).
+    """
+    y = np.asarray(y, dtype=np.float64)
+    sigma2 = noise_variance(snr_db)
+    if sigma2.ndim:
+        sigma2 = sigma2[..., None]
+    L = y / sigma2 if cfg.rule == RULE_R2 else (2 * y) / sigma2
+    if compat_prefix:
+        if cfg.rule == RULE_R1:
+            L[..., :PUNCTURE_PREFIX] = 1e-9
+        elif cfg.rule in (RULE_R3, RULE_R4):
+            L[..., :PUNCTURE_PREFIX] = 0.0
+    return L
