@@ -24,6 +24,7 @@ struct CsrDev {
 // index z inside its block row.
 //   row_info[e] = block column << 16 | shift
 //   col_info[k] = by-row position of the edge << 16 | pair bit (0x8000) | shift
+//   colr_info[k] = block row of the edge << 16 | pair bit (0x8000) | shift
 // The pair bit says that entry k+1 lies in the same block (a block that is the sum of two
 // circulants); which of the two checks has the smaller index then depends on the lane.
 struct QcDev {
@@ -32,6 +33,7 @@ struct QcDev {
     const unsigned *row_info;  // [Eb]
     const int *col_ptr;        // [nb+1]
     const unsigned *col_info;  // [Eb]
+    const unsigned *colr_info; // [Eb]
     int max_dc, max_dv;
 };
 
@@ -57,7 +59,7 @@ struct Launch {
 hipError_t launch_csr(const CsrDev &code, const ldpc_decode_config &cfg, int compute_dtype,
                       const Launch &io, int num_cus, void **workspace, size_t *workspace_bytes,
                       const char **kernel_name);
-// decode_qc.hip, one translation unit per rule (-DLDPC_QC_RULE=k)
+// decode_qc_r0.hip (rule 0) and decode_qc.hip, one translation unit per rule (-DLDPC_QC_RULE=k, k = 1..4)
 #define LDPC_DECL_QC(k)                                                                            \
     hipError_t launch_qc_rule_##k(const QcDev &code, const ldpc_decode_config &cfg,                \
                                   int compute_dtype, const Launch &io, int num_cus,                \

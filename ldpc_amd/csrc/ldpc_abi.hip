@@ -164,7 +164,7 @@ extern "C" int32_t ldpc_code_attach_qc(ldpc_code *c, int32_t mb, int32_t nb, int
         }
     }
     std::vector<int> row_ptr(mb + 1, 0), col_ptr(nb + 1, 0);
-    std::vector<unsigned> row_info(Eb), col_info(Eb);
+    std::vector<unsigned> row_info(Eb), col_info(Eb), colr_info(Eb);
     for (int e = 0; e < Eb; ++e) { row_ptr[er[e] + 1]++; col_ptr[ec[e] + 1]++; }
     for (int i = 0; i < mb; ++i) row_ptr[i + 1] += row_ptr[i];
     for (int i = 0; i < nb; ++i) col_ptr[i + 1] += col_ptr[i];
@@ -178,10 +178,12 @@ extern "C" int32_t ldpc_code_attach_qc(ldpc_code *c, int32_t mb, int32_t nb, int
         for (int e = 0; e < Eb; ++e) {  // ascending block row inside each column
             const int bc = ec[e], k = fill[bc]++;
             col_info[k] = ((unsigned)e << 16) | (unsigned)es[e];
+            colr_info[k] = ((unsigned)er[e] << 16) | (unsigned)es[e];
             if (last_row[bc] == er[e]) {
                 if (++run[bc] > 2)
                     return fail(LDPC_ERR_UNSUPPORTED, "block (%d,%d) is the sum of more than two circulants", er[e], bc);
                 col_info[k - 1] |= 0x8000u;
+                colr_info[k - 1] |= 0x8000u;
             } else {
                 run[bc] = 1;
             }
@@ -189,13 +191,14 @@ extern "C" int32_t ldpc_code_attach_qc(ldpc_code *c, int32_t mb, int32_t nb, int
         }
     }
     HIP_TRY(hipSetDevice(c->device));
-    const size_t total = (size_t)(mb + 1) + Eb + (nb + 1) + Eb;
+    const size_t total = (size_t)(mb + 1) + Eb + (nb + 1) + Eb + Eb;
     std::vector<int> host(total);
     int *p = host.data();
     std::copy(row_ptr.begin(), row_ptr.end(), p); p += mb + 1;
     std::memcpy(p, row_info.data(), Eb * sizeof(int)); p += Eb;
     std::copy(col_ptr.begin(), col_ptr.end(), p); p += nb + 1;
-    std::memcpy(p, col_info.data(), Eb * sizeof(int));
+    std::memcpy(p, col_info.data(), Eb * sizeof(int)); p += Eb;
+    std::memcpy(p, colr_info.data(), Eb * sizeof(int));
     if (c->d_qc) { (void)hipFree(c->d_qc); c->d_qc = nullptr; c->has_qc = false; }
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_qc), total * sizeof(int)));
     HIP_TRY(hipMemcpy(c->d_qc, host.data(), total * sizeof(int), hipMemcpyHostToDevice));
@@ -204,6 +207,7 @@ extern "C" int32_t ldpc_code_attach_qc(ldpc_code *c, int32_t mb, int32_t nb, int
     c->qc.row_info = reinterpret_cast<const unsigned *>(c->d_qc + (mb + 1));
     c->qc.col_ptr = c->d_qc + (mb + 1) + Eb;
     c->qc.col_info = reinterpret_cast<const unsigned *>(c->d_qc + (mb + 1) + Eb + (nb + 1));
+    c->qc.colr_info = reinterpret_cast<const unsigned *>(c->d_qc + (mb + 1) + Eb + (nb + 1) + Eb);
     c->qc.max_dc = max_dc; c->qc.max_dv = max_dv;
     c->has_qc = true;
     return LDPC_OK;
