@@ -1,0 +1,333 @@
+// Code-specialised circulant decoders: the base graph is a template parameter.
+//
+// `Code` (csrc/gen/codes_gen.h, generated from the packaged matrices) carries the circulant tables
+// as constant expressions, so the loops over block rows / block columns / edges are unrolled at
+// compile time: every shift and array offset is an immediate (rotated LDS addresses cost one or
+// two vector instructions instead of five), the per-variable state (channel LLR, own posterior)
+// sits in registers, and no table is read at run time.  A handle whose circulant description
+// equals a compiled-in code is routed here; any other code runs on the table-driven kernels.
+//
+// Thread mapping is that of the table-driven kernels: F frames ("slots") per workgroup, thread
+// tid = f*Z + z.  When the workgroup is a single wave (F*Z <= 64) no barrier is needed at all:
+// LDS operations of one wave execute in order, and per-slot decisions come from a ballot.
+//
+// Rule R0 (ldpc.py:137-227), compressed check state: the check-node phase stores per check
+// (m1 with the sign parity in its sign bit, m2); the variable-node phase rebuilds each message
+//      |r| = m2 if |b_i| == m1 else m1,   sign(r) = parity xor sign(b_i)      (ldpc.py:184-187)
+// and sums in ascending check order (ldpc.py:173,188), then b = 0.75 * (S + L) (ldpc.py:196).
+#include <cstring>
+
+#include "bp_common.h"
+#include "bp_math.h"
+#include "gen/codes_gen.h"
+
+namespace ldpc {
+
+template <int I> struct IC { static constexpr int value = I; constexpr operator int() const { return I; } };
+template <int B, int E, class Fn>
+__device__ __forceinline__ void static_for(Fn &&fn)
+{
+    if constexpr (B < E) { fn(IC<B>{}); static_for<B + 1, E>(fn); }
+}
+
+template <typename T> struct SNum;
+template <> struct SNum<float> {
+    typedef float2 Pair;
+    __device__ static __forceinline__ unsigned sign_word(float x) { return __float_as_uint(x); }
+    __device__ static __forceinline__ float with_sign(float mag, unsigned s) {
+        return __uint_as_float(__float_as_uint(mag) | (s & 0x80000000u));
+    }
+    // written out as instructions: the min/max builtins put a quieting canonicalisation in front
+    // of every operand that comes from memory
+    __device__ static __forceinline__ float min_abs(float m, float b) {
+        float d; asm("v_min_f32 %0, %1, |%2|" : "=v"(d) : "v"(m), "v"(b)); return d;
+    }
+    __device__ static __forceinline__ float second(float m1, float m2, float b) {  // m1 <= m2
+        float d; asm("v_med3_f32 %0, %1, %2, |%3|" : "=v"(d) : "v"(m1), "v"(m2), "v"(b)); return d;
+    }
+    __device__ static __forceinline__ Pair make(float a, float b) { return make_float2(a, b); }
+};
+template <> struct SNum<double> {
+    typedef double2 Pair;
+    __device__ static __forceinline__ unsigned sign_word(double x) { return (unsigned)__double2hiint(x); }
+    __device__ static __forceinline__ double with_sign(double mag, unsigned s) {
+        return __hiloint2double(__double2hiint(mag) | (int)(s & 0x80000000u), __double2loint(mag));
+    }
+    __device__ static __forceinline__ double min_abs(double m, double b) {
+        double d; asm("v_min_f64 %0, %1, |%2|" : "=v"(d) : "v"(m), "v"(b)); return d;
+    }
+    __device__ static __forceinline__ double second(double m1, double m2, double b) {
+        double t, d;
+        asm("v_max_f64 %0, %1, |%2|" : "=v"(t) : "v"(m1), "v"(b));
+        asm("v_min_f64 %0, %1, %2" : "=v"(d) : "v"(m2), "v"(t));
+        return d;
+    }
+    __device__ static __forceinline__ Pair make(double a, double b) { return make_double2(a, b); }
+};
+
+constexpr bool is_pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
+
+// byte offset of element ((z + s) mod Z) of a Z-vector with ELEM-byte elements, given zb = z*ELEM
+template <int Z, int ELEM, int S>
+__device__ __forceinline__ unsigned rot_fwd(unsigned zb)
+{
+    if constexpr (S == 0) return zb;
+    else if constexpr (is_pow2(Z)) return (zb + S * ELEM) & (unsigned)(Z * ELEM - 1);
+    else { const unsigned t = zb + S * ELEM; return min(t, t - (unsigned)(Z * ELEM)); }
+}
+// ... of element ((z - s) mod Z)
+template <int Z, int ELEM, int S>
+__device__ __forceinline__ unsigned rot_bwd(unsigned zb)
+{
+    return rot_fwd<Z, ELEM, (Z - S) % Z>(zb);
+}
+
+template <class C, typename T, int F>
+struct SpecLayout {
+    static constexpr int THREADS = ((F * C::Z + 63) / 64) * 64;
+    static constexpr bool SINGLE = THREADS == 64;
+    static constexpr int POST_BYTES = C::NB * C::Z * (int)sizeof(T);
+    static constexpr int CS_BYTES = C::MB * C::Z * 2 * (int)sizeof(T);
+    // slots are padded so that consecutive slots start 8 banks apart
+    static constexpr int SLOT_BYTES = ((POST_BYTES + CS_BYTES + 127) / 128) * 128 + (F > 1 ? 32 : 0);
+    static constexpr int FLAG_OFF = F * SLOT_BYTES;
+    static constexpr int LDS_BYTES = FLAG_OFF + 16 * (int)sizeof(int);
+};
+
+// ------------------------------------------------------------------------------------------ R0
+// check-node phase of one thread: every block row in turn.  Returns 1 if any of its checks fails
+// (FLOATCHK: the iteration-0 test of ldpc.py:158,165 on the raw LLR sums instead of the parity).
+template <class C, typename T, bool FLOATCHK>
+__device__ __forceinline__ int spec_r0_checks(const unsigned char *post_b, unsigned char *cs_b, unsigned zb, unsigned zp)
+{
+    typedef typename SNum<T>::Pair Pair;
+    constexpr int Z = C::Z, MB = C::MB, ST = sizeof(T), SP = 2 * sizeof(T);
+    int bad = 0;
+    static_for<0, MB>([&](auto br) {
+        constexpr int e0 = C::row_ptr[br], D = C::row_ptr[br + 1] - e0;
+        T m1 = Lim<T>::inf(), m2 = Lim<T>::inf();
+        unsigned sx = 0;
+        T fsum = (T)0;
+        static_for<0, D>([&](auto p) {
+            constexpr int bc = C::row_col[e0 + p], s = C::row_shift[e0 + p];
+            const T b = *reinterpret_cast<const T *>(post_b + bc * Z * ST + rot_fwd<Z, ST, s>(zb));
+            m2 = SNum<T>::second(m1, m2, b);
+            m1 = SNum<T>::min_abs(m1, b);
+            sx ^= SNum<T>::sign_word(b);
+            if constexpr (FLOATCHK) fsum += b;
+        });
+        if constexpr (D < 2) { m1 = (T)0; m2 = (T)0; }  // ldpc.py:178
+        *reinterpret_cast<Pair *>(cs_b + br * Z * SP + zp) = SNum<T>::make(SNum<T>::with_sign(m1, sx), m2);
+        if constexpr (FLOATCHK) bad |= !(t_fmod(fsum, (T)2) == (T)0);
+        else bad |= (int)(((unsigned)D ^ (sx >> 31)) & 1u);  // parity of the hard bits 1 - signbit
+    });
+    return bad;
+}
+
+template <class C, typename T, typename TL, int F>
+__global__ void __launch_bounds__((SpecLayout<C, T, F>::THREADS))
+spec_r0_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__restrict__ hard_out,
+               int *__restrict__ iters_out, uint8_t *__restrict__ conv_out, T *__restrict__ post_out)
+{
+    typedef SpecLayout<C, T, F> LY;
+    typedef typename SNum<T>::Pair Pair;
+    constexpr int Z = C::Z, NB = C::NB, MB = C::MB, ST = sizeof(T), SP = 2 * sizeof(T);
+    constexpr int n = NB * Z;
+    extern __shared__ __align__(16) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const bool lane_on = tid < F * Z;
+    const int f = lane_on ? tid / Z : 0;
+    const int z = lane_on ? tid - f * Z : 0;
+    unsigned char *slot = smem + f * LY::SLOT_BYTES;
+    unsigned char *post_b = slot;                  // [NB][Z] T
+    unsigned char *cs_b = slot + LY::POST_BYTES;   // [MB][Z] Pair
+    int *slot_bad = reinterpret_cast<int *>(smem + LY::FLAG_OFF);
+    const unsigned zb = (unsigned)z * ST, zp = (unsigned)z * SP;
+    unsigned long long slot_mask = ~0ull;
+    if constexpr (F * Z < 64 || F > 1) {
+        slot_mask = (Z >= 64 ? ~0ull : ((1ull << Z) - 1ull)) << ((f * Z) & 63);
+    }
+
+    const long long groups = (frames + F - 1) / F;
+    for (long long grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+        const long long frame = grp * F + f;
+        const bool active = lane_on && frame < frames;
+        T L[NB], own[NB];
+        static_for<0, NB>([&](auto bc) {
+            // + 0.0 turns -0.0 into +0.0: from here on "negative" is exactly "sign bit set"
+            const T l = (active ? (T)llr[frame * n + bc * Z + z] : (T)0) + (T)0;
+            L[bc] = l;
+            own[bc] = l;  // ldpc.py:154
+            *reinterpret_cast<T *>(post_b + bc * Z * ST + zb) = l;
+        });
+        if constexpr (!LY::SINGLE) {
+            if (tid < F) slot_bad[tid] = 0;
+            __syncthreads();
+        }
+
+        bool done = !active;
+        int t = 0;
+        int final_bad = 0;
+        for (; t <= g.max_iters; ++t) {
+            // the pass at t == max_iters only exists in fixed-work mode (final syndrome)
+            if (t == g.max_iters && g.early_exit) break;
+            const bool float_check = t == 0 && g.float_syndrome0 && g.early_exit;
+            int bad = 0;
+            if (!done) {
+                bad = float_check ? spec_r0_checks<C, T, true>(post_b, cs_b, zb, zp)
+                                  : spec_r0_checks<C, T, false>(post_b, cs_b, zb, zp);
+            }
+            // ---- does every check of my slot hold?
+            bool slot_ok;
+            if constexpr (LY::SINGLE) {
+                slot_ok = (__ballot(bad) & slot_mask) == 0ull;
+            } else {
+                if (bad && (g.early_exit || t == g.max_iters)) slot_bad[f] = 1;
+                __syncthreads();
+                slot_ok = slot_bad[f] == 0;
+            }
+            if (t == g.max_iters) { final_bad = !slot_ok; break; }
+            if (g.early_exit) {
+                if (!done && slot_ok) {  // ldpc.py:165-170
+                    static_for<0, NB>([&](auto bc) {
+                        const T v = own[bc];
+                        hard_out[frame * n + bc * Z + z] =
+                            float_check ? (v == (T)0 ? 0 : (v == (T)1 ? 1 : 2)) : (uint8_t)hard_bit<0>(v);
+                        if (post_out) post_out[frame * n + bc * Z + z] = v;
+                    });
+                    if (z == 0) { iters_out[frame] = t; conv_out[frame] = 1; }
+                    done = true;
+                }
+                if constexpr (LY::SINGLE) {
+                    if (__ballot(!done) == 0ull) break;
+                } else {
+                    if (!__syncthreads_or(!done)) break;
+                    if (tid < F) slot_bad[tid] = 0;
+                }
+            }
+            // ---- variable nodes
+            if (!done) {
+                static_for<0, NB>([&](auto bc) {
+                    constexpr int k0 = C::col_ptr[bc], D = C::col_ptr[bc + 1] - k0;
+                    const unsigned so = SNum<T>::sign_word(own[bc]);
+                    const T ao = t_abs(own[bc]);
+                    T r[D > 0 ? D : 1];
+                    unsigned off[D > 0 ? D : 1];
+                    static_for<0, D>([&](auto k) {
+                        constexpr int br = C::col_row[k0 + k], s = C::col_shift[k0 + k];
+                        off[k] = rot_bwd<Z, SP, s>(zp);
+                        const Pair c = *reinterpret_cast<const Pair *>(cs_b + br * Z * SP + off[k]);
+                        const T a1 = t_abs(c.x);
+                        const T mag = ao == a1 ? c.y : a1;
+                        r[k] = SNum<T>::with_sign(mag, SNum<T>::sign_word(c.x) ^ so);
+                    });
+                    static_for<0, (D > 0 ? D - 1 : 0)>([&](auto k) {
+                        if constexpr (C::col_pair[k0 + k] != 0) {  // lower check index first
+                            const bool sw = off[k] > off[k + 1];
+                            const T a = r[k], b = r[k + 1];
+                            r[k] = sw ? b : a;
+                            r[k + 1] = sw ? a : b;
+                        }
+                    });
+                    T s = (T)0;  // ldpc.py:173,188
+                    static_for<0, D>([&](auto k) { s += r[k]; });
+                    own[bc] = g.scale * (s + L[bc]);  // ldpc.py:196
+                    *reinterpret_cast<T *>(post_b + bc * Z * ST + zb) = own[bc];
+                });
+            }
+            if constexpr (!LY::SINGLE) __syncthreads();
+        }
+        if (!done) {  // ldpc.py:210-227
+            static_for<0, NB>([&](auto bc) {
+                hard_out[frame * n + bc * Z + z] = (uint8_t)hard_bit<0>(own[bc]);
+                if (post_out) post_out[frame * n + bc * Z + z] = own[bc];
+            });
+            if (z == 0) {
+                iters_out[frame] = g.early_exit ? g.max_iters - 1 : g.max_iters;
+                conv_out[frame] = g.early_exit ? 0 : (uint8_t)!final_bad;
+            }
+        }
+        if constexpr (!LY::SINGLE) __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------ host
+template <class C>
+static bool code_matches(int Z, int mb, int nb, int Eb, const int *er, const int *ec, const int *es)
+{
+    if (Z != C::Z || mb != C::MB || nb != C::NB || Eb != C::EB) return false;
+    for (int br = 0; br < mb; ++br)
+        for (int e = C::row_ptr[br]; e < C::row_ptr[br + 1]; ++e)
+            if (er[e] != br || ec[e] != C::row_col[e] || es[e] != C::row_shift[e]) return false;
+    return true;
+}
+
+template <class C, typename T, typename TL, int F>
+static hipError_t launch_spec_r0(const ldpc_decode_config &cfg, const Launch &io, int num_cus, const char **name)
+{
+    typedef SpecLayout<C, T, F> LY;
+    static_assert(LY::LDS_BYTES <= 160 * 1024, "LDS limit");
+    Cfg<T> g;
+    g.rule = 0; g.max_iters = cfg.max_iters; g.early_exit = cfg.early_exit;
+    g.float_syndrome0 = cfg.float_syndrome0; g.num_active_checks = -1; g.num_refresh_vars = -1;
+    g.scale = (T)cfg.scale; g.clip_tanh_arg = (T)0; g.clip_prod = (T)0; g.clip_post = (T)0;
+    size_t per_cu = (160 * 1024) / LY::LDS_BYTES;
+    const size_t wave_cap = 32 / (LY::THREADS / 64);
+    if (per_cu > wave_cap) per_cu = wave_cap;
+    const long long groups = (io.frames + F - 1) / F;
+    long long grid = (long long)num_cus * (long long)per_cu * 2;
+    if (grid > groups) grid = groups;
+    if (grid < 1) grid = 1;
+    auto k = spec_r0_kernel<C, T, TL, F>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LY::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(LY::THREADS), LY::LDS_BYTES, io.stream, g,
+                       reinterpret_cast<const TL *>(io.llr), io.frames, io.hard, io.iters, io.converged,
+                       reinterpret_cast<T *>(io.posterior));
+    *name = sizeof(T) == 8 ? "spec_r0_f64" : "spec_r0_f32";
+    return hipGetLastError();
+}
+
+template <class C, int F>
+static hipError_t launch_spec_code(const ldpc_decode_config &cfg, int compute_dtype, const Launch &io,
+                                   int num_cus, const char **name, bool *supported)
+{
+    *supported = true;
+    if (cfg.rule == 0) {
+        if (compute_dtype == LDPC_F64) {
+            if (io.llr_dtype == LDPC_F64) return launch_spec_r0<C, double, double, F>(cfg, io, num_cus, name);
+            return launch_spec_r0<C, double, float, F>(cfg, io, num_cus, name);
+        }
+        if (io.llr_dtype == LDPC_F32) return launch_spec_r0<C, float, float, F>(cfg, io, num_cus, name);
+    }
+    *supported = false;
+    return hipSuccess;
+}
+
+int spec_match(int Z, int mb, int nb, int Eb, const int *er, const int *ec, const int *es)
+{
+    int id = 0;
+#define LDPC_MATCH(CODE, SLOTS)                                       \
+    if (code_matches<CODE>(Z, mb, nb, Eb, er, ec, es)) return id;     \
+    ++id;
+    LDPC_FOR_EACH_SPEC_CODE(LDPC_MATCH)
+#undef LDPC_MATCH
+    return -1;
+}
+
+hipError_t launch_spec(int spec_id, const ldpc_decode_config &cfg, int compute_dtype, const Launch &io,
+                       int num_cus, const char **name, bool *supported)
+{
+    int id = 0;
+#define LDPC_LAUNCH(CODE, SLOTS)                                                                   \
+    if (spec_id == id) return launch_spec_code<CODE, SLOTS>(cfg, compute_dtype, io, num_cus, name, supported); \
+    ++id;
+    LDPC_FOR_EACH_SPEC_CODE(LDPC_LAUNCH)
+#undef LDPC_LAUNCH
+    *supported = false;
+    return hipSuccess;
+}
+
+}  // namespace ldpc

@@ -40,6 +40,7 @@ struct ldpc_code {
     int *d_ints = nullptr;  // one allocation: row_ptr | col_idx | col_ptr | csc_edge
     CsrDev csr{};
     bool has_qc = false;
+    int spec_id = -1;       // compiled-in specialisation of this code, if any
     QcDev qc{};
     int *d_qc = nullptr;    // one allocation: row_ptr | row_info | col_ptr | col_info
     void *workspace = nullptr;
@@ -210,6 +211,7 @@ extern "C" int32_t ldpc_code_attach_qc(ldpc_code *c, int32_t mb, int32_t nb, int
     c->qc.colr_info = reinterpret_cast<const unsigned *>(c->d_qc + (mb + 1) + Eb + (nb + 1) + Eb);
     c->qc.max_dc = max_dc; c->qc.max_dv = max_dv;
     c->has_qc = true;
+    c->spec_id = spec_match(Z, mb, nb, Eb, er, ec, es);
     return LDPC_OK;
 }
 
@@ -266,6 +268,12 @@ extern "C" int32_t ldpc_decode_batch(ldpc_code *c, const ldpc_decode_config *cfg
     if (kernel == LDPC_KERNEL_QC && !c->has_qc) return fail(LDPC_ERR_ARG, "no QC description attached to this code");
     if (kernel == LDPC_KERNEL_QC && quirks)
         return fail(LDPC_ERR_UNSUPPORTED, "num_active_checks / num_refresh_vars need the edge-list kernel");
+    if (kernel == LDPC_KERNEL_AUTO && c->has_qc && !quirks && c->spec_id >= 0) {
+        bool supported = false;
+        hipError_t e = launch_spec(c->spec_id, *cfg, compute_dtype, io, c->num_cus, &g_kernel, &supported);
+        if (e != hipSuccess) return fail(LDPC_ERR_HIP, "specialised kernel launch: %s", hipGetErrorString(e));
+        if (supported) return LDPC_OK;
+    }
     if (kernel != LDPC_KERNEL_CSR && c->has_qc && !quirks) {
         bool supported = false;
         hipError_t e = hipSuccess;

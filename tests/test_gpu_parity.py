@@ -19,7 +19,9 @@ from oracle import bp_oracle
 pytestmark = pytest.mark.gpu
 
 ALL = golden_files()
-KERNELS = {"csr": 1, "qc": 2}
+KERNELS = {"auto": 0, "csr": 1, "qc": 2}
+#: kernel-name prefixes each selector may resolve to (auto prefers a compiled-in specialisation)
+PREFIX = {"auto": ("spec", "qc"), "csr": ("csr",), "qc": ("qc",)}
 
 _decoders = {}
 
@@ -40,7 +42,7 @@ def _rel_err(a, b):
     return float(np.max(np.abs(a - b) / scale)) if a.size else 0.0
 
 
-@pytest.mark.parametrize("kernel", ["csr", "qc"])
+@pytest.mark.parametrize("kernel", ["auto", "csr", "qc"])
 @pytest.mark.parametrize("path", ALL, ids=_ids(ALL))
 def test_f64_matches_reference(path, kernel):
     g = load_golden(path)
@@ -48,7 +50,7 @@ def test_f64_matches_reference(path, kernel):
     dec = decoder_for(g["code"])
     L = bp_oracle.llr_from_samples(g["y"].astype(np.float64), g["snr_attr"], cfg.rule)
     res = dec.decode(L, cfg, compute_dtype=np.float64, want_posterior=True, kernel=KERNELS[kernel])
-    assert res.kernel.startswith(kernel), res.kernel
+    assert res.kernel.startswith(PREFIX[kernel]), res.kernel
     assert np.array_equal(res.converged, g["converged"])
     assert np.array_equal(res.iters, g["iters"])
     assert np.array_equal(res.hard, g["hard"].astype(np.uint8))
@@ -62,7 +64,7 @@ def test_f64_matches_reference(path, kernel):
     assert np.array_equal(ber[ok], g["ret"][ok])
 
 
-@pytest.mark.parametrize("kernel", ["csr", "qc"])
+@pytest.mark.parametrize("kernel", ["auto", "csr", "qc"])
 @pytest.mark.parametrize("path", ALL, ids=_ids(ALL))
 def test_f32_matches_reference(path, kernel):
     g = load_golden(path)
@@ -74,7 +76,7 @@ def test_f32_matches_reference(path, kernel):
     if cfg.rule != 1:                 # R1's punctured-prefix value 1e-9 is not a float32 value
         assert np.array_equal(L32.astype(np.float64), L)
     res = dec.decode(L32, cfg, compute_dtype=np.float32, want_posterior=True, kernel=KERNELS[kernel])
-    assert res.kernel.startswith(kernel), res.kernel
+    assert res.kernel.startswith(PREFIX[kernel]), res.kernel
     conv, iters = g["converged"][exact], g["iters"][exact]
     hard, post = g["hard"][exact].astype(np.uint8), g["posterior"][exact]
     if cfg.rule <= 1:
@@ -115,7 +117,7 @@ def test_f64_batch_matches_c_oracle(rule, name, c_oracle):
     L = bp_oracle.llr_from_samples(y, snr, cfg.rule)
     eh, ei, ec, ep = c_oracle.c_decode(code, cfg, L)
     dec = decoder_for(name)
-    for kernel in ("csr", "qc"):
+    for kernel in ("auto", "csr", "qc"):
         res = dec.decode(L, cfg, compute_dtype=np.float64, want_posterior=True, kernel=KERNELS[kernel])
         assert np.array_equal(res.converged, ec), kernel
         assert np.array_equal(res.iters, ei), kernel
@@ -133,7 +135,7 @@ def test_fixed_iterations_mode(c_oracle):
     for rule in ("R0", "R1"):
         cfg = config.PRESETS[rule].with_(max_iters=10, early_exit=False)
         eh, ei, ec, ep = c_oracle.c_decode(code, cfg, L)
-        for kernel in ("csr", "qc"):
+        for kernel in ("auto", "csr", "qc"):
             res = dec.decode(L, cfg, want_posterior=True, kernel=KERNELS[kernel])
             assert np.array_equal(res.iters, ei) and (res.iters == 10).all()
             assert np.array_equal(res.converged, ec)
