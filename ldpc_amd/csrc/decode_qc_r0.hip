@@ -6,7 +6,7 @@
 // smallest m2, parity of the signs) and of b_i itself:
 //      |r| = m2 if |b_i| == m1 else m1        sign(r) = parity xor sign(b_i)
 // (if two inputs tie for the smallest, m2 == m1 and both forms agree).  So the check-node phase
-// stores only (m1 with the parity in its sign bit, m2) per check, and the variable-node phase
+// stores only (m1, m2), both with the parity in their sign bit, per check, and the variable-node phase
 // rebuilds each message while summing in ascending check order (ldpc.py:173,188), then forms
 // b = 0.75 * (S + L) (ldpc.py:196).  Per frame the LDS holds b, L and the check pairs: 12 KiB for
 // the CCSDS (512,256) code in double precision instead of 26 KiB with one message per edge.
@@ -38,6 +38,9 @@ template <> struct Num<float> {
     }
     // min(m, |b|); the instruction is written out because the builtin inserts a quieting
     // canonicalisation in front of every operand that comes from memory
+    __device__ static __forceinline__ float flip_sign(float x, unsigned signbit) {
+        return __uint_as_float(__float_as_uint(x) ^ signbit);
+    }
     __device__ static __forceinline__ float min_abs(float m, float b) {
         float d; asm("v_min_f32 %0, %1, |%2|" : "=v"(d) : "v"(m), "v"(b)); return d;
     }
@@ -52,6 +55,9 @@ template <> struct Num<double> {
     __device__ static __forceinline__ unsigned sign_word(double x) { return (unsigned)__double2hiint(x); }
     __device__ static __forceinline__ double with_sign(double mag, unsigned s) {
         return __hiloint2double(__double2hiint(mag) | (int)(s & 0x80000000u), __double2loint(mag));
+    }
+    __device__ static __forceinline__ double flip_sign(double x, unsigned signbit) {
+        return __hiloint2double(__double2hiint(x) ^ (int)signbit, __double2loint(x));
     }
     __device__ static __forceinline__ double min_abs(double m, double b) {
         double d; asm("v_min_f64 %0, %1, |%2|" : "=v"(d) : "v"(m), "v"(b)); return d;
@@ -99,7 +105,7 @@ __device__ __forceinline__ int r0_check(const R0Ctx &x, const_u32 info, int e0, 
         if (FLOATCHK) fsum += b;
     }
     if (D < 2) { m1 = (T)0; m2 = (T)0; }  // ldpc.py:178: a check with one variable sends nothing
-    cs[br * x.FZ + x.tid] = Num<T>::make(Num<T>::with_sign(m1, sx), m2);
+    cs[br * x.FZ + x.tid] = Num<T>::make(Num<T>::with_sign(m1, sx), Num<T>::with_sign(m2, sx));
     if (FLOATCHK) return !(t_fmod(fsum, (T)2) == (T)0);  // ldpc.py:158,165 on the raw LLRs
     // parity of the hard decisions: hard = 1 - signbit, so the XOR is (D - #negative) mod 2
     return (int)(((unsigned)D ^ (sx >> 31)) & 1u);
@@ -112,7 +118,7 @@ __device__ __forceinline__ void r0_var(const R0Ctx &x, T scale, const_u32 info, 
 {
     const int vi = bc * x.FZ + x.tid;
     const T own = post[vi];
-    const unsigned so = Num<T>::sign_word(own);
+    const unsigned so = Num<T>::sign_word(own) & 0x80000000u;
     const T ao = t_abs(own);
     T r[D > 0 ? D : 1];
     int zz[D > 0 ? D : 1];
@@ -124,9 +130,7 @@ __device__ __forceinline__ void r0_var(const R0Ctx &x, T scale, const_u32 info, 
         pair[k] = (w & 0x8000u) != 0;
         zz[k] = rot_sub(x.z, s, x.Z);
         const typename Num<T>::Pair c = cs[br * x.FZ + x.fz0 + zz[k]];
-        const T a1 = t_abs(c.x);
-        const T mag = ao == a1 ? c.y : a1;
-        r[k] = Num<T>::with_sign(mag, Num<T>::sign_word(c.x) ^ so);
+        r[k] = Num<T>::flip_sign(ao == t_abs(c.x) ? c.y : c.x, so);  // candidates carry the parity
     }
 #pragma unroll
     for (int k = 0; k + 1 < D; ++k) {

@@ -12,7 +12,8 @@
 // LDS operations of one wave execute in order, and per-slot decisions come from a ballot.
 //
 // Rule R0 (ldpc.py:137-227), compressed check state: the check-node phase stores per check
-// (m1 with the sign parity in its sign bit, m2); the variable-node phase rebuilds each message
+// (m1, m2) = smallest and second smallest input magnitude, both carrying the parity of the input
+// signs in their sign bit; the variable-node phase rebuilds each message
 //      |r| = m2 if |b_i| == m1 else m1,   sign(r) = parity xor sign(b_i)      (ldpc.py:184-187)
 // and sums in ascending check order (ldpc.py:173,188), then b = 0.75 * (S + L) (ldpc.py:196).
 #include <cstring>
@@ -39,6 +40,9 @@ template <> struct SNum<float> {
     }
     // written out as instructions: the min/max builtins put a quieting canonicalisation in front
     // of every operand that comes from memory
+    __device__ static __forceinline__ float flip_sign(float x, unsigned signbit) {
+        return __uint_as_float(__float_as_uint(x) ^ signbit);
+    }
     __device__ static __forceinline__ float min_abs(float m, float b) {
         float d; asm("v_min_f32 %0, %1, |%2|" : "=v"(d) : "v"(m), "v"(b)); return d;
     }
@@ -52,6 +56,9 @@ template <> struct SNum<double> {
     __device__ static __forceinline__ unsigned sign_word(double x) { return (unsigned)__double2hiint(x); }
     __device__ static __forceinline__ double with_sign(double mag, unsigned s) {
         return __hiloint2double(__double2hiint(mag) | (int)(s & 0x80000000u), __double2loint(mag));
+    }
+    __device__ static __forceinline__ double flip_sign(double x, unsigned signbit) {
+        return __hiloint2double(__double2hiint(x) ^ (int)signbit, __double2loint(x));
     }
     __device__ static __forceinline__ double min_abs(double m, double b) {
         double d; asm("v_min_f64 %0, %1, |%2|" : "=v"(d) : "v"(m), "v"(b)); return d;
@@ -117,7 +124,8 @@ __device__ __forceinline__ int spec_r0_checks(const unsigned char *post_b, unsig
             if constexpr (FLOATCHK) fsum += b;
         });
         if constexpr (D < 2) { m1 = (T)0; m2 = (T)0; }  // ldpc.py:178
-        *reinterpret_cast<Pair *>(cs_b + br * Z * SP + zp) = SNum<T>::make(SNum<T>::with_sign(m1, sx), m2);
+        *reinterpret_cast<Pair *>(cs_b + br * Z * SP + zp) =
+            SNum<T>::make(SNum<T>::with_sign(m1, sx), SNum<T>::with_sign(m2, sx));
         if constexpr (FLOATCHK) bad |= !(t_fmod(fsum, (T)2) == (T)0);
         else bad |= (int)(((unsigned)D ^ (sx >> 31)) & 1u);  // parity of the hard bits 1 - signbit
     });
@@ -159,7 +167,7 @@ spec_r0_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *
             const T l = (active ? (T)llr[frame * n + bc * Z + z] : (T)0) + (T)0;
             L[bc] = l;
             own[bc] = l;  // ldpc.py:154
-            *reinterpret_cast<T *>(post_b + bc * Z * ST + zb) = l;
+            if (lane_on) *reinterpret_cast<T *>(post_b + bc * Z * ST + zb) = l;  // idle lanes alias lane 0
         });
         if constexpr (!LY::SINGLE) {
             if (tid < F) slot_bad[tid] = 0;
@@ -210,7 +218,7 @@ spec_r0_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *
             if (!done) {
                 static_for<0, NB>([&](auto bc) {
                     constexpr int k0 = C::col_ptr[bc], D = C::col_ptr[bc + 1] - k0;
-                    const unsigned so = SNum<T>::sign_word(own[bc]);
+                    const unsigned so = SNum<T>::sign_word(own[bc]) & 0x80000000u;
                     const T ao = t_abs(own[bc]);
                     T r[D > 0 ? D : 1];
                     unsigned off[D > 0 ? D : 1];
@@ -218,9 +226,8 @@ spec_r0_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *
                         constexpr int br = C::col_row[k0 + k], s = C::col_shift[k0 + k];
                         off[k] = rot_bwd<Z, SP, s>(zp);
                         const Pair c = *reinterpret_cast<const Pair *>(cs_b + br * Z * SP + off[k]);
-                        const T a1 = t_abs(c.x);
-                        const T mag = ao == a1 ? c.y : a1;
-                        r[k] = SNum<T>::with_sign(mag, SNum<T>::sign_word(c.x) ^ so);
+                        // both candidates already carry the check's sign parity
+                        r[k] = SNum<T>::flip_sign(ao == t_abs(c.x) ? c.y : c.x, so);
                     });
                     static_for<0, (D > 0 ? D - 1 : 0)>([&](auto k) {
                         if constexpr (C::col_pair[k0 + k] != 0) {  // lower check index first
@@ -249,6 +256,192 @@ spec_r0_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *
             }
         }
         if constexpr (!LY::SINGLE) __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------ R1
+// Rule R1 (bpsk.py:154-260): extrinsic normalised min-sum.  Single-wave workgroups only.
+//
+//   qv [EB][Z]  variable-to-check messages in VARIABLE order (k = position of the edge in its block
+//               column's list): written linearly by the variable (bc, z), read rotated by the check
+//   cs [MB][Z]  per check (m1, m2) = smallest / second smallest |q| with the sign parity of all
+//               inputs in both sign bits; the variable rebuilds its message as
+//               0.75 * (m2 if |q_own| == m1 else m1), sign = parity xor sign(q_own)  (bpsk.py:221-233)
+// The variable keeps its own q per edge (registers when they fit, else re-read from qv), sums the
+// rebuilt messages in ascending check order and writes q = L + (sum of the others) (bpsk.py:244-247).
+// Hard decisions (`0 if b > 0 else 1`, bpsk.py:240-243) never touch memory: a ballot per block
+// column gives a 64-bit mask in scalar registers, and the syndrome of block row br is the XOR of
+// those masks rotated by the circulant shifts — a handful of scalar instructions per base edge.
+template <int Z, int F>
+constexpr unsigned long long replicate_field(unsigned long long x)
+{
+    unsigned long long r = 0;
+    for (int f = 0; f < F; ++f) r |= x << (f * Z);
+    return r;
+}
+// bit (f*Z + z) of the result = bit (f*Z + (z + S) mod Z) of m, for every slot f
+template <int Z, int F, int S>
+__device__ __forceinline__ unsigned long long rot_fields(unsigned long long m)
+{
+    if constexpr (S == 0) return m;
+    else if constexpr (Z == 64) return (m >> S) | (m << (64 - S));
+    else {
+        constexpr unsigned long long field = (1ull << Z) - 1ull;
+        constexpr unsigned long long low = replicate_field<Z, F>(field >> S);
+        constexpr unsigned long long high = replicate_field<Z, F>(field & ~(field >> S));
+        return ((m >> S) & low) | ((m << (Z - S)) & high);
+    }
+}
+
+template <class C, typename T, int F>
+struct R1Layout {
+    static constexpr int THREADS = ((F * C::Z + 63) / 64) * 64;
+    static constexpr int QV_BYTES = C::EB * C::Z * (int)sizeof(T);
+    static constexpr int CS_BYTES = C::MB * C::Z * 2 * (int)sizeof(T);
+    static constexpr int SLOT_BYTES = ((QV_BYTES + CS_BYTES + 127) / 128) * 128 + (F > 1 ? 32 : 0);
+    static constexpr int LDS_BYTES = F * SLOT_BYTES;
+    static constexpr bool QREG = C::EB * (int)sizeof(T) / 4 <= 72;  // own messages in registers
+};
+
+template <class C, int F>
+__device__ __forceinline__ bool r1_slot_ok(const unsigned long long (&hm)[C::NB], unsigned long long slot_mask)
+{
+    unsigned long long bad = 0ull;
+    static_for<0, C::MB>([&](auto br) {
+        constexpr int e0 = C::row_ptr[br], D = C::row_ptr[br + 1] - e0;
+        unsigned long long acc = 0ull;
+        static_for<0, D>([&](auto p) {
+            acc ^= rot_fields<C::Z, F, C::row_shift[e0 + p]>(hm[C::row_col[e0 + p]]);
+        });
+        bad |= acc;
+    });
+    return (bad & slot_mask) == 0ull;
+}
+
+template <class C, typename T, typename TL, int F>
+__global__ void __launch_bounds__(64)
+spec_r1_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__restrict__ hard_out,
+               int *__restrict__ iters_out, uint8_t *__restrict__ conv_out, T *__restrict__ post_out)
+{
+    typedef R1Layout<C, T, F> LY;
+    typedef typename SNum<T>::Pair Pair;
+    static_assert(LY::THREADS == 64, "single-wave workgroups only");
+    constexpr int Z = C::Z, NB = C::NB, MB = C::MB, EB = C::EB, ST = sizeof(T), SP = 2 * sizeof(T);
+    constexpr int n = NB * Z;
+    extern __shared__ __align__(16) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const bool lane_on = tid < F * Z;
+    const int f = lane_on ? tid / Z : 0;
+    const int z = lane_on ? tid - f * Z : 0;
+    unsigned char *qv_b = smem + f * LY::SLOT_BYTES;  // [EB][Z] T, variable order
+    unsigned char *cs_b = qv_b + LY::QV_BYTES;        // [MB][Z] Pair
+    const unsigned zb = (unsigned)z * ST, zp = (unsigned)z * SP;
+    const unsigned long long slot_mask = (Z >= 64 ? ~0ull : ((1ull << (Z & 63)) - 1ull)) << ((f * Z) & 63);
+
+    const long long groups = (frames + F - 1) / F;
+    for (long long grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+        const long long frame = grp * F + f;
+        const bool active = lane_on && frame < frames;
+        T L[NB], own[NB];
+        T q[LY::QREG ? EB : 1];
+        unsigned long long hm[NB];
+        static_for<0, NB>([&](auto bc) {
+            constexpr int k0 = C::col_ptr[bc], D = C::col_ptr[bc + 1] - k0;
+            const T l = active ? (T)llr[frame * n + bc * Z + z] : (T)0;
+            L[bc] = l;
+            own[bc] = l;
+            hm[bc] = __ballot(!(l > (T)0));
+            static_for<0, D>([&](auto k) {  // bpsk.py:170-177
+                if constexpr (LY::QREG) q[k0 + k] = l;
+                if (lane_on) *reinterpret_cast<T *>(qv_b + (k0 + k) * Z * ST + zb) = l;  // idle lanes alias lane 0
+            });
+        });
+
+        auto write_out = [&](int iters, int conv) {
+            static_for<0, NB>([&](auto bc) {
+                hard_out[frame * n + bc * Z + z] = (uint8_t)hard_bit<1>(own[bc]);
+                if (post_out) post_out[frame * n + bc * Z + z] = own[bc];
+            });
+            if (z == 0) { iters_out[frame] = iters; conv_out[frame] = (uint8_t)conv; }
+        };
+
+        bool done = !active;
+        int t = 0;
+        for (; t < g.max_iters; ++t) {
+            if (g.early_exit) {  // bpsk.py:205-209
+                const bool ok = r1_slot_ok<C, F>(hm, slot_mask);
+                if (!done && ok) { write_out(t, 1); done = true; }
+                if (__ballot(!done) == 0ull) break;
+            }
+            if (!done) {
+                // ---- check nodes (bpsk.py:213-233)
+                static_for<0, MB>([&](auto br) {
+                    constexpr int e0 = C::row_ptr[br], D = C::row_ptr[br + 1] - e0;
+                    T m1 = Lim<T>::inf(), m2 = Lim<T>::inf();
+                    unsigned sx = 0;
+                    static_for<0, D>([&](auto p) {
+                        constexpr int kpos = C::row_kpos[e0 + p], s = C::row_shift[e0 + p];
+                        const T v = *reinterpret_cast<const T *>(qv_b + kpos * Z * ST + rot_fwd<Z, ST, s>(zb));
+                        m2 = SNum<T>::second(m1, m2, v);
+                        m1 = SNum<T>::min_abs(m1, v);
+                        sx ^= SNum<T>::sign_word(v);
+                    });
+                    if constexpr (D < 2) { m1 = (T)0; m2 = (T)0; }  // bpsk.py:216
+                    *reinterpret_cast<Pair *>(cs_b + br * Z * SP + zp) =
+                        SNum<T>::make(SNum<T>::with_sign(m1, sx), SNum<T>::with_sign(m2, sx));
+                });
+                // ---- variable nodes (bpsk.py:235-247)
+                static_for<0, NB>([&](auto bc) {
+                    constexpr int k0 = C::col_ptr[bc], D = C::col_ptr[bc + 1] - k0;
+                    T r[D > 0 ? D : 1], qn[D > 0 ? D : 1];
+                    unsigned off[D > 0 ? D : 1];
+                    static_for<0, D>([&](auto k) {
+                        constexpr int br = C::col_row[k0 + k], s = C::col_shift[k0 + k];
+                        T qo;
+                        if constexpr (LY::QREG) qo = q[k0 + k];
+                        else qo = *reinterpret_cast<const T *>(qv_b + (k0 + k) * Z * ST + zb);
+                        off[k] = rot_bwd<Z, SP, s>(zp);
+                        const Pair c = *reinterpret_cast<const Pair *>(cs_b + br * Z * SP + off[k]);
+                        const T sel = t_abs(qo) == t_abs(c.x) ? c.y : c.x;
+                        r[k] = SNum<T>::flip_sign(g.scale * sel, SNum<T>::sign_word(qo) & 0x80000000u);
+                    });
+                    bool sw[D > 0 ? D : 1];
+                    static_for<0, (D > 0 ? D - 1 : 0)>([&](auto k) {
+                        if constexpr (C::col_pair[k0 + k] != 0) {  // lower check index first
+                            sw[k] = off[k] > off[k + 1];
+                            const T a = r[k], b = r[k + 1];
+                            r[k] = sw[k] ? b : a;
+                            r[k + 1] = sw[k] ? a : b;
+                        }
+                    });
+                    T run = (T)0;
+                    static_for<0, D>([&](auto k) {
+                        T ext = run;
+                        static_for<k + 1, D>([&](auto kk) { ext += r[kk]; });
+                        run += r[k];
+                        qn[k] = L[bc] + ext;
+                    });
+                    static_for<0, (D > 0 ? D - 1 : 0)>([&](auto k) {
+                        if constexpr (C::col_pair[k0 + k] != 0) {
+                            const T a = qn[k], b = qn[k + 1];
+                            qn[k] = sw[k] ? b : a;
+                            qn[k + 1] = sw[k] ? a : b;
+                        }
+                    });
+                    static_for<0, D>([&](auto k) {
+                        if constexpr (LY::QREG) q[k0 + k] = qn[k];
+                        *reinterpret_cast<T *>(qv_b + (k0 + k) * Z * ST + zb) = qn[k];
+                    });
+                    own[bc] = L[bc] + run;  // bpsk.py:237
+                    hm[bc] = __ballot(!(own[bc] > (T)0));
+                });
+            }
+        }
+        if (!done) {  // bpsk.py:251-260
+            if (g.early_exit) write_out(g.max_iters - 1, 0);
+            else write_out(g.max_iters, r1_slot_ok<C, F>(hm, slot_mask) ? 1 : 0);
+        }
     }
 }
 
@@ -290,6 +483,31 @@ static hipError_t launch_spec_r0(const ldpc_decode_config &cfg, const Launch &io
     return hipGetLastError();
 }
 
+template <class C, typename T, typename TL, int F>
+static hipError_t launch_spec_r1(const ldpc_decode_config &cfg, const Launch &io, int num_cus, const char **name)
+{
+    typedef R1Layout<C, T, F> LY;
+    Cfg<T> g;
+    g.rule = 1; g.max_iters = cfg.max_iters; g.early_exit = cfg.early_exit;
+    g.float_syndrome0 = 0; g.num_active_checks = -1; g.num_refresh_vars = -1;
+    g.scale = (T)cfg.scale; g.clip_tanh_arg = (T)0; g.clip_prod = (T)0; g.clip_post = (T)0;
+    size_t per_cu = (160 * 1024) / LY::LDS_BYTES;
+    if (per_cu > 32) per_cu = 32;
+    const long long groups = (io.frames + F - 1) / F;
+    long long grid = (long long)num_cus * (long long)per_cu * 2;
+    if (grid > groups) grid = groups;
+    if (grid < 1) grid = 1;
+    auto k = spec_r1_kernel<C, T, TL, F>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LY::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(64), LY::LDS_BYTES, io.stream, g,
+                       reinterpret_cast<const TL *>(io.llr), io.frames, io.hard, io.iters, io.converged,
+                       reinterpret_cast<T *>(io.posterior));
+    *name = sizeof(T) == 8 ? "spec_r1_f64" : "spec_r1_f32";
+    return hipGetLastError();
+}
+
 template <class C, int F>
 static hipError_t launch_spec_code(const ldpc_decode_config &cfg, int compute_dtype, const Launch &io,
                                    int num_cus, const char **name, bool *supported)
@@ -301,6 +519,15 @@ static hipError_t launch_spec_code(const ldpc_decode_config &cfg, int compute_dt
             return launch_spec_r0<C, double, float, F>(cfg, io, num_cus, name);
         }
         if (io.llr_dtype == LDPC_F32) return launch_spec_r0<C, float, float, F>(cfg, io, num_cus, name);
+    }
+    if constexpr (R1Layout<C, double, F>::THREADS == 64 && R1Layout<C, double, F>::LDS_BYTES <= 160 * 1024) {
+        if (cfg.rule == 1) {
+            if (compute_dtype == LDPC_F64) {
+                if (io.llr_dtype == LDPC_F64) return launch_spec_r1<C, double, double, F>(cfg, io, num_cus, name);
+                return launch_spec_r1<C, double, float, F>(cfg, io, num_cus, name);
+            }
+            if (io.llr_dtype == LDPC_F32) return launch_spec_r1<C, float, float, F>(cfg, io, num_cus, name);
+        }
     }
     *supported = false;
     return hipSuccess;
