@@ -31,6 +31,25 @@ class LdpcError(RuntimeError):
 _lib = None
 
 
+def _share_hip_runtime_with_torch() -> None:
+    """PyTorch wheels carry their own copy of the HIP runtime (torch/lib/libamdhip64.so, soname
+    libamdhip64.so.7).  Two copies in one process cannot both own the GPU, and device pointers and
+    streams are only meaningful inside the runtime that made them.  Loading torch's copy first
+    makes this library (which asks for that soname) bind to it, whichever of the two the caller
+    imports first; without torch the system runtime under /opt/rocm is used."""
+    import importlib.util
+
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+
+
 def load() -> ctypes.CDLL:
     global _lib
     if _lib is not None:
@@ -38,6 +57,7 @@ def load() -> ctypes.CDLL:
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: build it with `python -m ldpc_amd.build` "
                           "(hipcc, --offload-arch=gfx950); there is no CPU fallback")
+    _share_hip_runtime_with_torch()
     lib = ctypes.CDLL(LIB_PATH)
     vp, i32, i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
     lib.ldpc_last_error.restype = ctypes.c_char_p

@@ -53,10 +53,9 @@ __global__ void decode_csr_kernel(CsrDev c, Cfg<T> g, const TL *__restrict__ llr
             hb[i] = (uint8_t)hard_bit<RULE>(l);
         }
         __syncthreads();
-        if (RULE == 0) {
-            for (int e = tid; e < E; e += NT) c2v[e] = (T)0;  // rows never visited contribute 0
-        } else {
-            for (int e = tid; e < E; e += NT) v2c[e] = L[c.col_idx[e]];  // bpsk.py:172-177
+        for (int e = tid; e < E; e += NT) {
+            c2v[e] = (T)0;  // checks that are never visited (inactive rows, degree < 2) contribute 0
+            if (RULE != 0) v2c[e] = L[c.col_idx[e]];  // bpsk.py:172-177
         }
         __syncthreads();
 
