@@ -20,6 +20,7 @@ Rank 0 prints one JSON line.  Beside the headline value it carries
   other         secondary workloads (early exit at an operating SNR, float32, rule R1), N=1 only
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -39,6 +40,22 @@ def lds_bytes_per_frame_iter(code, rule, itemsize):
     E, n = code.num_edges, code.n
     per4 = (12 * E + 4 * n) if rule == 0 else 16 * E
     return per4 * itemsize // 4
+
+
+def measured_traffic(args, frames):
+    """HBM bytes per launch from the hardware counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3
+    passes, corrected as profiles/*_hbm_traffic.json says), scaled to this launch's frame count;
+    None when no counter run is on file for this workload."""
+    key = f"{args.code}/{args.rule}/{args.dtype}/f32llr"
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json"))):
+        try:
+            rec = json.load(open(path))["workloads"].get(key)
+        except (OSError, ValueError, KeyError):
+            rec = None
+        if rec:
+            best = rec["hbm_bytes_per_frame"] * frames
+    return best
 
 
 def timed_steps(fn, steps, warmup, torch, dist, world):
@@ -128,8 +145,8 @@ def main():
     executed = stats["iterations"] + stats["not_converged"]     # failures ran max_iters, report max-1
     lds_bytes = lds_bytes_per_frame_iter(code, cfg.rule, 8 if args.dtype == "f64" else 4) * executed / world
     roofline = {"bound": "hbm", "achieved": hbm_bytes / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "traffic": None, "kernel": kernel_name[0], "kernel_ms": kernel_ms,
-                "bytes_per_frame": 5 * code.n + 5}
+                "unit": "GB/s", "traffic": measured_traffic(args, args.frames), "kernel": kernel_name[0],
+                "kernel_ms": kernel_ms, "bytes_per_frame": 5 * code.n + 5}
     roofline["frac"] = roofline["achieved"] / roofline["peak"]
     lds = {"bound": "lds", "achieved": lds_bytes / (kernel_ms * 1e-3) / 1e9, "peak": LDS_PEAK_GBS,
            "unit": "GB/s", "bytes_per_frame_iter": lds_bytes_per_frame_iter(code, cfg.rule, 8 if args.dtype == "f64" else 4)}
