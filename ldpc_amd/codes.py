@@ -234,6 +234,28 @@ def compile_code(H: np.ndarray, name: str = "code", find_qc: bool = True) -> Com
     return code
 
 
+def compile_qc(qc: QCStructure, name: str = "qc") -> CompiledCode:
+    """Edge lists straight from a circulant description (no dense matrix is formed: the lifted 5G
+    graphs are hundreds of megabytes dense)."""
+    Z = qc.Z
+    z = np.arange(Z)
+    rows = (qc.edge_row[:, None].astype(np.int64) * Z + z[None, :]).ravel()
+    cols = (qc.edge_col[:, None].astype(np.int64) * Z + (z[None, :] + qc.edge_shift[:, None]) % Z).ravel()
+    m, n = qc.mb * Z, qc.nb * Z
+    o = np.lexsort((cols, rows))
+    rows, cols = rows[o], cols[o]
+    if len(rows) > 1 and ((np.diff(rows) == 0) & (np.diff(cols) == 0)).any():
+        raise ValueError("repeated edge in the circulant description")
+    row_ptr = np.zeros(m + 1, np.int32)
+    np.cumsum(np.bincount(rows, minlength=m), out=row_ptr[1:])
+    order = np.lexsort((rows, cols))
+    col_ptr = np.zeros(n + 1, np.int32)
+    np.cumsum(np.bincount(cols, minlength=n), out=col_ptr[1:])
+    digest = hashlib.sha256(np.stack([rows, cols]).astype(np.int32).tobytes()).hexdigest()[:16]
+    return CompiledCode(name, m, n, row_ptr, cols.astype(np.int32), col_ptr, rows[order].astype(np.int32),
+                        order.astype(np.int32), qc, digest, None)
+
+
 # --------------------------------------------------------------------------- GF(2) generator
 def gf2_generator(H: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
     """Generator matrix G (k x n, uint8) with H @ G.T == 0 (mod 2), and the k information
@@ -319,6 +341,12 @@ _cache = {}
 
 def load_packaged(name: str) -> CompiledCode:
     """One of the reference's own matrices, shipped as an edge list under ldpc_amd/data."""
+    if name == "nr_bg1_z384" and name not in _cache:
+        # build-authored (see nr_bg1.py): BG1 connectivity, synthetic information-part shifts
+        from . import nr_bg1
+        _cache[name] = compile_qc(nr_bg1.build(), name)
+    if name in _cache:
+        return _cache[name]
     if name not in PACKAGED:
         raise KeyError(f"unknown packaged code {name!r}; have {sorted(PACKAGED)}")
     if name not in _cache:

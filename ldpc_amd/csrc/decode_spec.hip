@@ -132,8 +132,17 @@ __device__ __forceinline__ int spec_r0_checks(const unsigned char *post_b, unsig
     return bad;
 }
 
+#ifndef LDPC_SPEC_WAVES
+#define LDPC_SPEC_WAVES 0
+#endif
+#if LDPC_SPEC_WAVES > 0
+#define LDPC_SPEC_OCC __attribute__((amdgpu_waves_per_eu(LDPC_SPEC_WAVES, LDPC_SPEC_WAVES)))
+#else
+#define LDPC_SPEC_OCC
+#endif
+
 template <class C, typename T, typename TL, int F>
-__global__ void __launch_bounds__((SpecLayout<C, T, F>::THREADS))
+__global__ void __launch_bounds__((SpecLayout<C, T, F>::THREADS)) LDPC_SPEC_OCC
 spec_r0_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__restrict__ hard_out,
                int *__restrict__ iters_out, uint8_t *__restrict__ conv_out, T *__restrict__ post_out)
 {
@@ -319,7 +328,7 @@ __device__ __forceinline__ bool r1_slot_ok(const unsigned long long (&hm)[C::NB]
 }
 
 template <class C, typename T, typename TL, int F>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64) LDPC_SPEC_OCC
 spec_r1_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__restrict__ hard_out,
                int *__restrict__ iters_out, uint8_t *__restrict__ conv_out, T *__restrict__ post_out)
 {
