@@ -32,6 +32,16 @@ extern "C" {
 #define LDPC_RULE_R2 2 /* /root/reference/bpsk.py:263-387    sumProductDecodeTest(codeword)       */
 #define LDPC_RULE_R3 3 /* /root/reference/channel.py:402-513 sumProductDecodeTest(codeword)       */
 #define LDPC_RULE_R4 4 /* /root/reference/channel.py:260-398 sumProductDecode(codeword) + phi     */
+/*
+ * Row-layered normalised min-sum.  NO counterpart in the reference (it only has flooding
+ * schedules); a build extension for the large 5G codes whose flooding messages do not fit on
+ * chip.  Checks are visited in ascending order; each takes q = P - r_old from the current
+ * posteriors P, forms r_new = scale * min-of-the-others * sign-product-of-the-others and writes
+ * P = q + r_new back at once.  Iteration count, syndrome test at the top of each iteration, LLR
+ * polarity and hard decision are those of R1.  Circulant codes without double-circulant blocks
+ * only (all checks of a block row then touch distinct variables).
+ */
+#define LDPC_RULE_LNMS 5
 
 #define LDPC_F32 0
 #define LDPC_F64 1

@@ -9,8 +9,8 @@ from __future__ import annotations
 import ctypes
 from dataclasses import dataclass, replace
 
-RULE_R0, RULE_R1, RULE_R2, RULE_R3, RULE_R4 = range(5)
-RULE_NAMES = {"R0": 0, "R1": 1, "R2": 2, "R3": 3, "R4": 4}
+RULE_R0, RULE_R1, RULE_R2, RULE_R3, RULE_R4, RULE_LNMS = range(6)
+RULE_NAMES = {"R0": 0, "R1": 1, "R2": 2, "R3": 3, "R4": 4, "LNMS": 5}
 
 
 @dataclass(frozen=True)
@@ -56,7 +56,11 @@ R3 = DecodeConfig(rule=RULE_R3, max_iters=50, scale=0.85, clip_prod=0.99999999, 
 #: channel.py:260-398 — 40 iterations (channel.py:306), clip channel.py:367
 R4 = DecodeConfig(rule=RULE_R4, max_iters=40, scale=1.0, clip_post=500.0)
 
-PRESETS = {"R0": R0, "R1": R1, "R2": R2, "R3": R3, "R4": R4}
+#: row-layered normalised min-sum, alpha 0.75, 10 iterations: build extension, nothing in the
+#: reference corresponds to it (see include/ldpc_amd.h)
+LNMS = DecodeConfig(rule=RULE_LNMS, max_iters=10, scale=0.75)
+
+PRESETS = {"R0": R0, "R1": R1, "R2": R2, "R3": R3, "R4": R4, "LNMS": LNMS}
 
 
 class CDecodeConfig(ctypes.Structure):

@@ -2,7 +2,8 @@
 //
 // One frame per workgroup.  Messages of the frame live in LDS when they fit (160 KiB per CU),
 // otherwise in a per-workgroup slice of a global workspace; channel LLRs, posteriors and hard
-// bits always live in LDS.  Threads stride over checks in the check-node phase and over
+// bits live in LDS too unless even they do not fit (NR BG1 Z = 384 in double), in which case the
+// whole state of the frame goes to the workspace.  Threads stride over checks in the check-node phase and over
 // variables in the variable-node phase; the edge lists are read from global memory (shared by
 // every frame, so they stay in L2).  This is the general path and the one that honours the
 // reference's loop-bound quirks (num_active_checks, num_refresh_vars); codes with circulant
@@ -18,7 +19,8 @@
 
 namespace ldpc {
 
-template <int RULE, typename T, typename TL, bool LDSMSG>
+template <int RULE, typename T, typename TL, int WHERE>  // 0: all state in LDS, 1: messages in the
+                                                         // global workspace, 2: everything there
 __global__ void decode_csr_kernel(CsrDev c, Cfg<T> g, const TL *__restrict__ llr, long long frames,
                                   uint8_t *__restrict__ hard_out, int *__restrict__ iters_out,
                                   uint8_t *__restrict__ conv_out, T *__restrict__ post_out,
@@ -30,18 +32,29 @@ __global__ void decode_csr_kernel(CsrDev c, Cfg<T> g, const TL *__restrict__ llr
     const int mact = (g.num_active_checks < 0 || g.num_active_checks > m) ? m : g.num_active_checks;
     const int nref = (g.num_refresh_vars < 0 || g.num_refresh_vars > n) ? n : g.num_refresh_vars;
 
-    T *L = reinterpret_cast<T *>(smem);
-    T *post = L + n;
-    T *c2v, *v2c;
+    const size_t msg_elems = (size_t)(RULE == 0 ? E : 2 * E);
+    T *L, *post, *c2v, *v2c;
     uint8_t *hb;
-    if (LDSMSG) {
+    if (WHERE == 0) {
+        L = reinterpret_cast<T *>(smem);
+        post = L + n;
         c2v = post + n;
         v2c = c2v + E;  // unused by R0
-        hb = reinterpret_cast<uint8_t *>(RULE == 0 ? c2v + E : v2c + E);
-    } else {
+        hb = reinterpret_cast<uint8_t *>(c2v + msg_elems);
+    } else if (WHERE == 1) {
+        L = reinterpret_cast<T *>(smem);
+        post = L + n;
         hb = reinterpret_cast<uint8_t *>(post + n);
-        c2v = gws + (size_t)blockIdx.x * (size_t)(RULE == 0 ? E : 2 * E);
+        c2v = gws + (size_t)blockIdx.x * msg_elems;
         v2c = c2v + E;
+    } else {
+        // per workgroup: messages | L | post | hard bytes (rounded up to whole T)
+        const size_t per_wg = msg_elems + 2 * (size_t)n + ((size_t)n + sizeof(T) - 1) / sizeof(T);
+        c2v = gws + (size_t)blockIdx.x * per_wg;
+        v2c = c2v + E;
+        L = c2v + msg_elems;
+        post = L + n;
+        hb = reinterpret_cast<uint8_t *>(post + n);
     }
 
     for (long long f = blockIdx.x; f < frames; f += gridDim.x) {
@@ -197,20 +210,21 @@ static hipError_t launch_csr_t(const CsrDev &code, const ldpc_decode_config &cfg
 {
     const size_t msgs = (size_t)(RULE == 0 ? 1 : 2) * code.E * sizeof(T);
     const size_t base = (size_t)2 * code.n * sizeof(T) + (size_t)code.n + 16;
-    const bool in_lds = base + msgs <= kLdsLimit;
-    const size_t lds = in_lds ? base + msgs : base;
-    if (lds > kLdsLimit) return hipErrorInvalidValue;
+    const int where = base + msgs <= kLdsLimit ? 0 : (base <= kLdsLimit ? 1 : 2);
+    const size_t lds = where == 0 ? base + msgs : (where == 1 ? base : 16);
     int nt = 64;
     const int widest = code.n > code.m ? code.n : code.m;
     while (nt < 512 && nt * 2 <= widest) nt *= 2;
     const size_t per_cu = kLdsLimit / lds;
     long long resident = (long long)num_cus * (long long)(per_cu > 8 ? 8 : (per_cu < 1 ? 1 : per_cu));
     long long grid = io.frames < resident * 4 ? io.frames : resident * 4;
-    if (!in_lds) grid = io.frames < resident ? io.frames : resident;
+    if (where != 0) grid = io.frames < resident ? io.frames : resident;
     if (grid < 1) grid = 1;
     T *gws = nullptr;
-    if (!in_lds) {
-        size_t need = (size_t)grid * msgs;
+    if (where != 0) {
+        const size_t hard_elems = ((size_t)code.n + sizeof(T) - 1) / sizeof(T);
+        const size_t per_wg = where == 1 ? msgs : msgs + ((size_t)2 * code.n + hard_elems) * sizeof(T);
+        size_t need = (size_t)grid * per_wg;
         if (*workspace_bytes < need) {
             if (*workspace) (void)hipFree(*workspace);
             *workspace = nullptr; *workspace_bytes = 0;
@@ -221,26 +235,19 @@ static hipError_t launch_csr_t(const CsrDev &code, const ldpc_decode_config &cfg
         gws = reinterpret_cast<T *>(*workspace);
     }
     Cfg<T> g = make_cfg<T>(cfg);
-    if (in_lds) {
-        auto k = decode_csr_kernel<RULE, T, TL, true>;
+    auto go = [&](auto k, const char *n64, const char *n32) -> hipError_t {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(nt), lds, io.stream, code, g,
                            reinterpret_cast<const TL *>(io.llr), io.frames, io.hard, io.iters,
                            io.converged, reinterpret_cast<T *>(io.posterior), gws);
-        *kernel_name = sizeof(T) == 8 ? "csr_lds_f64" : "csr_lds_f32";
-    } else {
-        auto k = decode_csr_kernel<RULE, T, TL, false>;
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(nt), lds, io.stream, code, g,
-                           reinterpret_cast<const TL *>(io.llr), io.frames, io.hard, io.iters,
-                           io.converged, reinterpret_cast<T *>(io.posterior), gws);
-        *kernel_name = sizeof(T) == 8 ? "csr_global_f64" : "csr_global_f32";
-    }
-    return hipGetLastError();
+        *kernel_name = sizeof(T) == 8 ? n64 : n32;
+        return hipGetLastError();
+    };
+    if (where == 0) return go(decode_csr_kernel<RULE, T, TL, 0>, "csr_lds_f64", "csr_lds_f32");
+    if (where == 1) return go(decode_csr_kernel<RULE, T, TL, 1>, "csr_global_f64", "csr_global_f32");
+    return go(decode_csr_kernel<RULE, T, TL, 2>, "csr_global_all_f64", "csr_global_all_f32");
 }
 
 template <typename T, typename TL>

@@ -238,7 +238,7 @@ extern "C" int32_t ldpc_code_info(const ldpc_code *c, int32_t *m, int32_t *n, in
 static int check_cfg(const ldpc_decode_config *cfg)
 {
     if (!cfg) return fail(LDPC_ERR_ARG, "cfg is NULL");
-    if (cfg->rule < 0 || cfg->rule > 4) return fail(LDPC_ERR_ARG, "rule %d is not one of R0..R4", cfg->rule);
+    if (cfg->rule < 0 || cfg->rule > LDPC_RULE_LNMS) return fail(LDPC_ERR_ARG, "rule %d is not one of R0..R4 or LNMS", cfg->rule);
     if (cfg->max_iters < 1 || cfg->max_iters > 100000) return fail(LDPC_ERR_ARG, "max_iters %d out of range", cfg->max_iters);
     if ((cfg->rule == 2 || cfg->rule == 3) && !(cfg->clip_prod > 0.0 && cfg->clip_prod <= 1.0))
         return fail(LDPC_ERR_ARG, "clip_prod must lie in (0, 1] for the tanh rules");
@@ -274,6 +274,9 @@ extern "C" int32_t ldpc_decode_batch(ldpc_code *c, const ldpc_decode_config *cfg
         if (e != hipSuccess) return fail(LDPC_ERR_HIP, "specialised kernel launch: %s", hipGetErrorString(e));
         if (supported) return LDPC_OK;
     }
+    if (cfg->rule == LDPC_RULE_LNMS)
+        return fail(LDPC_ERR_UNSUPPORTED, "layered min-sum needs a compiled-in circulant code without double-circulant blocks "
+                                          "(and float arithmetic when the posteriors exceed LDS in double)");
     if (kernel != LDPC_KERNEL_CSR && c->has_qc && !quirks) {
         bool supported = false;
         hipError_t e = hipSuccess;

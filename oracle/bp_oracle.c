@@ -15,6 +15,7 @@
  *   R3  /root/reference/channel.py:402-513  0.85-scaled tanh-rule sum-product
  *   R4  /root/reference/channel.py:260-398  phi-function sum-product
  *   syndrome: /root/reference/ldpc.py:76-80
+ *   LNMS row-layered normalised min-sum: a build extension with no counterpart in the reference
  *
  * Build: make -C oracle   (gcc -O2 -fopenmp -shared)
  */
@@ -230,7 +231,7 @@ int bp_oracle_decode(const oracle_code *code, const oracle_cfg *cfg, const doubl
                      int64_t frames, uint8_t *hard, int32_t *iters, uint8_t *converged,
                      double *posterior, int nthreads)
 {
-    if (!code || !cfg || cfg->rule < 0 || cfg->rule > 4 || cfg->max_iters < 1) return -1;
+    if (!code || !cfg || cfg->rule < 0 || cfg->rule > 4 || cfg->max_iters < 1) return -1; /* layered: bp_oracle_decode_lnms */
     for (int j = 0; j < code->m; j++)
         if (code->row_ptr[j + 1] - code->row_ptr[j] > 64) return -1;
 #ifdef _OPENMP
@@ -253,6 +254,82 @@ int bp_oracle_decode(const oracle_code *code, const oracle_cfg *cfg, const doubl
             if (posterior) memcpy(posterior + f * n, b, sizeof(double) * n);
         }
         free(b); free(S); free(q); free(r);
+    }
+    return 0;
+}
+
+/* ---------------------------------------------------------------- row-layered normalised min-sum
+ * Build extension (nothing in the reference corresponds to it): checks in ascending order, each
+ * working on the current posteriors.  Generated for double and for float so that the float GPU
+ * kernel has a bit-exact CPU counterpart.  The channel LLR is stored as L + 0 (no -0.0 anywhere,
+ * so "negative" and "sign bit set" coincide).
+ */
+#define DEFINE_LNMS(NAME, REAL, FABS)                                                              \
+    static void NAME(const oracle_code *c, const oracle_cfg *g, const double *Lin, REAL *P, REAL *R, \
+                     uint8_t *hard, int32_t *iters, uint8_t *conv)                                 \
+    {                                                                                              \
+        const int n = c->n, m = c->m;                                                              \
+        const REAL scale = (REAL)g->scale;                                                         \
+        REAL q[64];                                                                                \
+        for (int i = 0; i < n; i++) { P[i] = (REAL)Lin[i] + (REAL)0; hard[i] = P[i] > 0 ? 0 : 1; } \
+        for (int e = 0; e < c->E; e++) R[e] = (REAL)0;                                             \
+        *conv = 0;                                                                                 \
+        for (int t = 0; t < g->max_iters; t++) {                                                   \
+            if (g->early_exit && syndrome_ok(c, hard)) { *iters = t; *conv = 1; return; }          \
+            for (int j = 0; j < m; j++) {                                                          \
+                const int e0 = c->row_ptr[j], d = c->row_ptr[j + 1] - e0;                          \
+                if (d < 2) continue;                                                               \
+                REAL m1 = INFINITY, m2 = INFINITY;                                                 \
+                int neg = 0;                                                                       \
+                for (int p = 0; p < d; p++) {                                                      \
+                    q[p] = P[c->col_idx[e0 + p]] - R[e0 + p];                                      \
+                    REAL a = FABS(q[p]);                                                           \
+                    if (a < m1) { m2 = m1; m1 = a; } else if (a < m2) { m2 = a; }                  \
+                    neg ^= q[p] < 0;                                                               \
+                }                                                                                  \
+                const REAL A = scale * m1, B = scale * m2;                                         \
+                for (int p = 0; p < d; p++) {                                                      \
+                    REAL mag = FABS(q[p]) == m1 ? B : A;                                           \
+                    REAL r = (neg ^ (q[p] < 0)) ? -mag : mag;                                      \
+                    R[e0 + p] = r;                                                                 \
+                    P[c->col_idx[e0 + p]] = q[p] + r;                                              \
+                }                                                                                  \
+            }                                                                                      \
+            for (int i = 0; i < n; i++) hard[i] = P[i] > 0 ? 0 : 1;                                \
+        }                                                                                          \
+        if (g->early_exit) { *iters = g->max_iters - 1; *conv = 0; }                               \
+        else { *iters = g->max_iters; *conv = (uint8_t)syndrome_ok(c, hard); }                     \
+    }
+DEFINE_LNMS(decode_lnms_f64, double, fabs)
+DEFINE_LNMS(decode_lnms_f32, float, fabsf)
+
+/* Layered decode; use_float selects float arithmetic (posteriors are returned as doubles). */
+int bp_oracle_decode_lnms(const oracle_code *code, const oracle_cfg *cfg, const double *llr,
+                          int64_t frames, uint8_t *hard, int32_t *iters, uint8_t *converged,
+                          double *posterior, int nthreads, int use_float)
+{
+    if (!code || !cfg || cfg->max_iters < 1) return -1;
+    for (int j = 0; j < code->m; j++)
+        if (code->row_ptr[j + 1] - code->row_ptr[j] > 64) return -1;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+    const int n = code->n, E = code->E;
+#pragma omp parallel
+    {
+        void *P = malloc(sizeof(double) * (size_t)n);
+        void *R = malloc(sizeof(double) * (size_t)E);
+#pragma omp for schedule(dynamic, 2)
+        for (int64_t f = 0; f < frames; f++) {
+            if (use_float) {
+                decode_lnms_f32(code, cfg, llr + f * n, (float *)P, (float *)R, hard + f * n, iters + f, converged + f);
+                if (posterior) for (int i = 0; i < n; i++) posterior[f * n + i] = ((float *)P)[i];
+            } else {
+                decode_lnms_f64(code, cfg, llr + f * n, (double *)P, (double *)R, hard + f * n, iters + f, converged + f);
+                if (posterior) memcpy(posterior + f * n, P, sizeof(double) * n);
+            }
+        }
+        free(P); free(R);
     }
     return 0;
 }

@@ -299,8 +299,84 @@ def _load_c():
         _clib.bp_oracle_decode.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                            ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
                                            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        _clib.bp_oracle_decode_lnms.restype = ctypes.c_int
+        _clib.bp_oracle_decode_lnms.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                                ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
+                                                ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
         _clib.bp_oracle_max_threads.restype = ctypes.c_int
     return _clib
+
+
+def numpy_decode_lnms(code, cfg, llr, dtype=np.float64):
+    """Row-layered normalised min-sum (build extension, no counterpart in the reference): checks in
+    ascending order on the current posteriors; q = P - r_old, r_new = scale * min-of-others * sign,
+    P = q + r_new.  Syndrome test at the top of each iteration, R1's polarity and conventions."""
+    L = np.array(llr, dtype=np.float64, ndmin=2)
+    B, n = L.shape
+    P = L.astype(dtype) + dtype(0)
+    R = np.zeros((B, code.num_edges), dtype)
+    scale = dtype(cfg.scale)
+    hard = np.where(P > 0, 0, 1).astype(np.uint8)
+    iters = np.full(B, cfg.max_iters - 1 if cfg.early_exit else cfg.max_iters, np.int32)
+    conv = np.zeros(B, bool)
+    live = np.ones(B, bool)
+    hard_out = hard.copy()
+    post_out = P.copy()
+    for t in range(cfg.max_iters):
+        if cfg.early_exit:
+            ok = code.is_codeword(hard) & live
+            iters[ok] = t
+            conv[ok] = True
+            hard_out[ok] = hard[ok]
+            post_out[ok] = P[ok]
+            live &= ~ok
+            if not live.any():
+                break
+        for j in range(code.m):
+            e0, e1 = code.row_ptr[j], code.row_ptr[j + 1]
+            d = e1 - e0
+            if d < 2:
+                continue
+            cols = code.col_idx[e0:e1]
+            q = P[:, cols] - R[:, e0:e1]
+            a = np.abs(q)
+            srt = np.sort(a, axis=1)
+            m1, m2 = srt[:, 0], srt[:, 1]
+            neg = (q < 0)
+            par = np.logical_xor.reduce(neg, axis=1)
+            mag = np.where(a == m1[:, None], (scale * m2)[:, None], (scale * m1)[:, None])
+            r = np.where(par[:, None] ^ neg, -mag, mag).astype(dtype)
+            R[:, e0:e1] = r
+            P[:, cols] = q + r
+        hard = np.where(P > 0, 0, 1).astype(np.uint8)
+    hard_out[live] = hard[live]
+    post_out[live] = P[live]
+    if not cfg.early_exit:
+        conv = code.is_codeword(hard)
+    return hard_out, iters, conv, post_out.astype(np.float64)
+
+
+def c_decode_lnms(code, cfg, llr, nthreads: int = 0, use_float: bool = False, want_posterior: bool = True):
+    lib = _load_c()
+    L = np.ascontiguousarray(np.array(llr, dtype=np.float64, ndmin=2))
+    B, n = L.shape
+    assert n == code.n
+    arrs = [np.ascontiguousarray(a, dtype=np.int32) for a in
+            (code.row_ptr, code.col_idx, code.col_ptr, code.csc_edge)]
+    ccode = _OracleCode(code.m, code.n, code.num_edges, *[a.ctypes.data for a in arrs])
+    ccfg = _OracleCfg(int(cfg.rule), int(cfg.max_iters), int(bool(cfg.early_exit)), 0, -1, -1,
+                      float(cfg.scale), 0.0, 0.0, 0.0)
+    hard = np.zeros((B, n), np.uint8)
+    iters = np.zeros(B, np.int32)
+    conv = np.zeros(B, np.uint8)
+    post = np.zeros((B, n), np.float64) if want_posterior else None
+    rc = lib.bp_oracle_decode_lnms(ctypes.byref(ccode), ctypes.byref(ccfg), L.ctypes.data, B,
+                                   hard.ctypes.data, iters.ctypes.data, conv.ctypes.data,
+                                   post.ctypes.data if post is not None else None, int(nthreads),
+                                   int(bool(use_float)))
+    if rc != 0:
+        raise ValueError("bp_oracle_decode_lnms rejected its arguments")
+    return hard, iters, conv.astype(bool), post
 
 
 def c_max_threads() -> int:

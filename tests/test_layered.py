@@ -1,0 +1,101 @@
+"""Row-layered normalised min-sum (build extension; no counterpart in the reference, so parity is
+against this build's own CPU restatements only) and the build-authored NR BG1 Z = 384 code."""
+import numpy as np
+import pytest
+
+from ldpc_amd import codes, config
+from oracle import bp_oracle
+
+SNR = {"wifi648": 0.5, "nr_bg2_z40": -5.5, "nr_bg2_z40_r1400": -4.0, "nr_bg1_z384": -0.5}
+
+
+def llrs(code, name, frames, seed):
+    rng = np.random.default_rng(seed)
+    s2 = 1 / (2 * 10 ** (SNR[name] / 10))
+    y = 1.0 + np.sqrt(s2) * rng.standard_normal((frames, code.n))     # all-zero codeword, bit 0 -> +1
+    return ((2 * y) / s2).astype(np.float32).astype(np.float64)
+
+
+def test_bg1_structure():
+    from ldpc_amd import nr_bg1
+    nr_bg1.self_check()
+    c = codes.load_packaged("nr_bg1_z384")
+    assert (c.m, c.n, c.num_edges, c.max_check_degree, c.max_var_degree) == (17664, 26112, 121344, 19, 30)
+    q = c.qc
+    assert (q.Z, q.mb, q.nb, q.num_base_edges) == (384, 46, 68, 316)
+    shifts = -np.ones((46, 68), int)
+    shifts[q.edge_row, q.edge_col] = q.edge_shift
+    assert not nr_bg1._has_4cycle(nr_bg1.BG1_ROWS, shifts, 384)
+    assert c.is_codeword(np.zeros((1, c.n), np.uint8)).all()
+    deg = np.diff(c.col_ptr)
+    assert (deg[26 * 384:] == 1).all()                       # extension parity columns
+
+
+@pytest.mark.parametrize("name", ["wifi648", "nr_bg2_z40"])
+def test_numpy_and_c_layered_oracles_agree(name, c_oracle):
+    code = codes.load_packaged(name)
+    L = llrs(code, name, 6, 1)
+    for use_float, dt in ((False, np.float64), (True, np.float32)):
+        a = c_oracle.c_decode_lnms(code, config.LNMS, L, use_float=use_float)
+        b = bp_oracle.numpy_decode_lnms(code, config.LNMS, L, dtype=dt)
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    fixed = config.LNMS.with_(early_exit=False, max_iters=4)
+    a = c_oracle.c_decode_lnms(code, fixed, L)
+    b = bp_oracle.numpy_decode_lnms(code, fixed, L)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b)) and (a[1] == 4).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["wifi648", "nr_bg2_z40", "nr_bg2_z40_r1400", "nr_bg1_z384"])
+def test_layered_kernel_matches_oracle(name, c_oracle):
+    from ldpc_amd import _lib
+    from ldpc_amd.decoder import Decoder
+    code = codes.load_packaged(name)
+    dec = Decoder(code)
+    frames = 96 if name == "nr_bg1_z384" else 384
+    L = llrs(code, name, frames, 3)
+    for cfg in (config.LNMS, config.LNMS.with_(early_exit=False, max_iters=5)):
+        eh, ei, ec, ep = c_oracle.c_decode_lnms(code, cfg, L, use_float=True)
+        res = dec.decode(L.astype(np.float32), cfg, compute_dtype=np.float32, want_posterior=True)
+        assert res.kernel == "spec_lnms_f32"
+        assert np.array_equal(res.iters, ei) and np.array_equal(res.converged, ec)
+        assert np.array_equal(res.hard, eh)
+        assert np.array_equal(res.posterior.astype(np.float64), ep)
+        if cfg.early_exit:
+            assert 0 < ec.sum()
+        if name == "nr_bg1_z384":
+            # posteriors of this code do not fit LDS in double
+            with pytest.raises(_lib.LdpcError) as ei_:
+                dec.decode(L, cfg, compute_dtype=np.float64)
+            assert ei_.value.code == _lib.LDPC_ERR_UNSUPPORTED
+            continue
+        eh, ei, ec, ep = c_oracle.c_decode_lnms(code, cfg, L)
+        res = dec.decode(L, cfg, compute_dtype=np.float64, want_posterior=True)
+        assert res.kernel == "spec_lnms_f64"
+        assert np.array_equal(res.iters, ei) and np.array_equal(res.converged, ec)
+        assert np.array_equal(res.hard, eh) and np.array_equal(res.posterior, ep)
+
+
+@pytest.mark.gpu
+def test_layered_refused_for_double_circulant_code():
+    from ldpc_amd import _lib
+    from ldpc_amd.decoder import Decoder
+    dec = Decoder(codes.load_packaged("ccsds512"))
+    with pytest.raises(_lib.LdpcError) as ei:
+        dec.decode(np.ones((1, 512)), config.LNMS)
+    assert ei.value.code == _lib.LDPC_ERR_UNSUPPORTED
+
+
+@pytest.mark.gpu
+def test_flooding_rules_on_bg1_through_the_global_workspace(c_oracle):
+    """BG1's flooding messages exceed LDS: the edge-list kernel keeps them in its global workspace."""
+    from ldpc_amd.decoder import Decoder
+    code = codes.load_packaged("nr_bg1_z384")
+    dec = Decoder(code)
+    L = llrs(code, "nr_bg1_z384", 8, 5)
+    for cfg in (config.R0.with_(max_iters=4), config.R1.with_(max_iters=6)):
+        Lr = -L if cfg.rule == 0 else L
+        eh, ei, ec, ep = c_oracle.c_decode(code, cfg, Lr)
+        res = dec.decode(Lr, cfg, want_posterior=True)
+        assert res.kernel.startswith("csr_global")
+        assert np.array_equal(res.iters, ei) and np.array_equal(res.hard, eh) and np.array_equal(res.posterior, ep)
