@@ -38,7 +38,7 @@ LDS_PEAK_GBS = 128 * 256 * 2.4   # 128 B/clk/CU x 256 CUs x 2.4 GHz = 78.6 TB/s 
 def lds_bytes_per_frame_iter(code, rule, itemsize):
     """Algorithmic LDS traffic of one flooding iteration of one frame."""
     E, n = code.num_edges, code.n
-    per4 = (12 * E + 4 * n) if rule == 0 else 16 * E
+    per4 = (12 * E + 4 * n) if rule == 0 else (8 * E + 24 * code.m if rule == 5 else 16 * E)
     return per4 * itemsize // 4
 
 
@@ -89,7 +89,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames", type=int, default=1 << 20, help="frames per launch per GPU")
+    ap.add_argument("--frames", type=int, default=0, help="frames per launch per GPU (0: 2^20 for the "
+                    "small codes, as many as give about 3 GiB of LLRs for the large ones)")
     ap.add_argument("--code", default="ccsds512")
     ap.add_argument("--rule", default="R0")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
@@ -118,8 +119,13 @@ def main():
     from ldpc_amd.decoder import Decoder
 
     code = codes.load_packaged(args.code)
-    G = codes.load_packaged_generator(args.code)
-    k_info = G.shape[0]
+    if args.code == "nr_bg1_z384":
+        G, k_info = None, code.n - code.m      # all-zero codeword; the dual-diagonal parity part has full rank
+    else:
+        G = codes.load_packaged_generator(args.code)
+        k_info = G.shape[0]
+    if args.frames <= 0:
+        args.frames = 1 << 20 if code.n <= 1024 else max(1024, (3 << 30) // (4 * code.n) // 1024 * 1024)
     cfg = config.PRESETS[args.rule].with_(max_iters=args.max_iters)
     compute = np.float64 if args.dtype == "f64" else np.float32
     dec = Decoder(code)
@@ -158,7 +164,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
         "data": "synthetic",
         "config": {"workload": f"{args.code} (n={code.n}, k={k_info}) x {args.frames} frames/launch/GPU, "
-                               f"rule {args.rule} ({'ldpc.py' if args.rule == 'R0' else 'bpsk.py'} decoder), "
+                               f"rule {args.rule} ({ {'R0': 'ldpc.py decoder', 'R1': 'bpsk.py decoder', 'LNMS': 'layered min-sum, build extension'}.get(args.rule, 'sum-product') }), "
                                f"max {args.max_iters} iterations, syndrome check per iteration, Es/N0 {args.snr} dB",
                    "code": args.code, "frames_per_launch_per_gpu": args.frames, "rule": args.rule,
                    "max_iters": args.max_iters, "early_exit": True, "es_n0_db": args.snr,
@@ -170,7 +176,7 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(code, cfg, batch, k_info, args)
-    if rank == 0 and world == 1 and not args.no_other:
+    if rank == 0 and world == 1 and not args.no_other and args.code == "ccsds512":
         out["other"] = other_workloads(code, G, dec, args, torch, dist, device)
     if world > 1:
         dist.barrier()
@@ -185,29 +191,52 @@ def cpu_baseline(code, cfg, batch, k_info, args):
     from oracle import bp_oracle
     bp_oracle.build_c_oracle()
     threads = min(bp_oracle.c_max_threads(), len(os.sched_getaffinity(0)), 64)
-    probe = 64 * threads
+    if cfg.rule == 5:
+        decode = lambda x: bp_oracle.c_decode_lnms(code, cfg, x, nthreads=threads, use_float=args.dtype == "f32",
+                                                   want_posterior=False)
+    else:
+        decode = lambda x: bp_oracle.c_decode(code, cfg, x, nthreads=threads, want_posterior=False)
+    probe = (64 if code.n <= 1024 else 2) * threads
     L = batch.llr[:probe].cpu().numpy().astype(np.float64)
     t0 = time.perf_counter()
-    bp_oracle.c_decode(code, cfg, L, nthreads=threads, want_posterior=False)
+    decode(L)
     rate = probe / max(time.perf_counter() - t0, 1e-6)
     sample = args.cpu_sample or int(min(batch.llr.shape[0], max(probe, rate * 15.0)))
     L = batch.llr[:sample].cpu().numpy().astype(np.float64)
     t0 = time.perf_counter()
-    hard, iters, conv, _ = bp_oracle.c_decode(code, cfg, L, nthreads=threads, want_posterior=False)
+    hard, iters, conv, _ = decode(L)
     dt = time.perf_counter() - t0
     same = (np.array_equal(hard, batch.hard[:sample].cpu().numpy())
             and np.array_equal(iters, batch.iters[:sample].cpu().numpy())
             and np.array_equal(conv, batch.converged[:sample].cpu().numpy().astype(bool)))
     return {"value": sample * k_info / dt / 1e9, "unit": "Gbit/s", "cores": threads, "kind": "port",
-            "sample": f"first {sample} frames of the same LLR batch, float64, oracle/bp_oracle.c with "
+            "sample": f"first {sample} frames of the same LLR batch, "
+                      f"{'float32' if (cfg.rule == 5 and args.dtype == 'f32') else 'float64'}, oracle/bp_oracle.c with "
                       f"{threads} OpenMP threads, {dt:.1f} s",
-            "gpu_results_identical_on_sample": bool(same) if args.dtype == "f64" else None}
+            "gpu_results_identical_on_sample": bool(same) if (args.dtype == "f64" or cfg.rule == 5) else None}
 
 
 def other_workloads(code, G, dec, args, torch, dist, device):
-    from ldpc_amd import config, sweep
+    """Secondary workloads, 3 timed launches each.  `frames` are per launch."""
+    from ldpc_amd import codes, config, sweep
+    from ldpc_amd.decoder import Decoder
     res = {}
+
+    def run(label, code_, G_, dec_, rule, dtype, snr, early, frames, k_info):
+        cfg = config.PRESETS[rule].with_(max_iters=args.max_iters, early_exit=early)
+        batch = sweep.make_batch(code_, G_, frames, snr, cfg, seed=[8, len(label)], device=device)
+        compute = np.float64 if dtype == "f64" else np.float32
+        wall, dev_ms = timed_steps(lambda: sweep.decode_batch(dec_, batch, cfg, compute_dtype=compute),
+                                   3, 1, torch, dist, 1)
+        sweep.count_errors(dec_, batch)
+        torch.cuda.synchronize()
+        st = sweep.summarize(batch.counters.cpu().numpy(), code_.n)
+        res[label] = {"gbit_s": frames * 3 * k_info / wall / 1e9, "mean_iters": st["mean_iters"],
+                      "fer": st["fer"], "ber": st["ber"], "frames": frames, "code": code_.name, "rule": rule,
+                      "dtype": dtype, "es_n0_db": snr, "early_exit": early}
+
     frames = min(args.frames, 1 << 19)
+    k = G.shape[0]
     for label, rule, dtype, snr, early in [
         ("R0_f64_es_n0_1dB", "R0", "f64", 1.0, True),
         ("R0_f32_worst_case", "R0", "f32", args.snr, True),
@@ -216,17 +245,12 @@ def other_workloads(code, G, dec, args, torch, dist, device):
         ("R1_f32_worst_case", "R1", "f32", args.snr, True),
         ("R0_f64_fixed_10", "R0", "f64", args.snr, False),
     ]:
-        cfg = config.PRESETS[rule].with_(max_iters=args.max_iters, early_exit=early)
-        batch = sweep.make_batch(code, G, frames, snr, cfg, seed=[8, len(label)], device=device)
-        compute = np.float64 if dtype == "f64" else np.float32
-        wall, dev_ms = timed_steps(lambda: sweep.decode_batch(dec, batch, cfg, compute_dtype=compute),
-                                   3, 1, torch, dist, 1)
-        sweep.count_errors(dec, batch)
-        torch.cuda.synchronize()
-        st = sweep.summarize(batch.counters.cpu().numpy(), code.n)
-        res[label] = {"gbit_s": frames * 3 * G.shape[0] / wall / 1e9, "mean_iters": st["mean_iters"],
-                      "fer": st["fer"], "ber": st["ber"], "frames": frames}
-        del batch
+        run(label, code, G, dec, rule, dtype, snr, early, frames, k)
+    # the build-authored NR BG1 Z=384 code under row-layered min-sum (float; see ldpc_amd/nr_bg1.py)
+    bg1 = codes.load_packaged("nr_bg1_z384")
+    dec1 = Decoder(bg1)
+    run("BG1_Z384_LNMS_f32_fixed_10", bg1, None, dec1, "LNMS", "f32", -3.0, False, 16384, bg1.n - bg1.m)
+    run("BG1_Z384_LNMS_f32_es_n0_-3dB", bg1, None, dec1, "LNMS", "f32", -3.0, True, 16384, bg1.n - bg1.m)
     return res
 
 
