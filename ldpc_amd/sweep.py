@@ -119,3 +119,31 @@ def summarize(counters: np.ndarray, n: int) -> dict:
     c["ber"] = c["bit_errors"] / (frames * n)         # over all n code bits (ldpc.py:166-170)
     c["mean_iters"] = c["iterations"] / frames
     return c
+
+
+def ber_sweep(code: CompiledCode, G: Optional[np.ndarray], cfg: DecodeConfig, snrs_db, frames_per_point: int,
+              device, compute_dtype=np.float64, seed=0, dec: Optional[Decoder] = None, batch: int = 1 << 18):
+    """Monte-Carlo error-rate sweep, the batched form of the reference's ``plotFrameError``
+    (ldpc.py:637-667): per SNR point decode ``frames_per_point`` random frames on this rank, count
+    on the device, sum the counters over ranks.  Returns one summary dict per SNR point."""
+    import torch
+
+    dec = dec or Decoder(code)
+    out = []
+    for si, snr in enumerate(snrs_db):
+        total = torch.zeros((5,), dtype=torch.int64, device=device)
+        left, chunk = frames_per_point, 0
+        while left > 0:
+            b = min(left, batch)
+            bt = make_batch(code, G, b, float(snr), cfg, seed=[seed, si, chunk], device=device)
+            decode_batch(dec, bt, cfg, compute_dtype=compute_dtype)
+            count_errors(dec, bt)
+            total += bt.counters
+            left -= b
+            chunk += 1
+        allreduce_counters(total)
+        torch.cuda.synchronize()
+        summ = summarize(total.cpu().numpy(), code.n)
+        summ["es_n0_db"] = float(snr)
+        out.append(summ)
+    return out

@@ -1,0 +1,44 @@
+"""Error-rate curves against the reference's own Monte-Carlo run (the
+reference ldpc.py decoder on CCSDS (512,256), 200 random codewords per point, Es/N0 0..4 dB).
+The GPU sweep uses far more frames; its frame-error rate must lie inside the Clopper-Pearson
+interval of the reference's counts, and float32 must tell the same story as float64."""
+import numpy as np
+import pytest
+from scipy.stats import beta
+
+from ldpc_amd import codes, config
+
+pytestmark = pytest.mark.gpu
+
+#: Es/N0 dB -> (frames, non-converged frames, mean numIterations) measured with the reference
+REFERENCE_R0_CCSDS = {0.0: (200, 63, 7.46), 1.0: (200, 1, 4.23), 2.0: (200, 0, 2.60), 3.0: (200, 0, 1.64), 4.0: (200, 0, 1.15)}
+
+
+def clopper_pearson(k, n, conf=0.999):
+    a = 1 - conf
+    lo = 0.0 if k == 0 else beta.ppf(a / 2, k, n - k + 1)
+    hi = 1.0 if k == n else beta.ppf(1 - a / 2, k + 1, n - k)
+    return lo, hi
+
+
+def test_r0_ccsds_fer_inside_reference_interval():
+    import torch
+    from ldpc_amd import sweep
+    code = codes.load_packaged("ccsds512")
+    G = codes.load_packaged_generator("ccsds512")
+    dev = torch.device("cuda", 0)
+    snrs = sorted(REFERENCE_R0_CCSDS)
+    r64 = sweep.ber_sweep(code, G, config.R0, snrs, 200_000, dev, np.float64, seed=11)
+    r32 = sweep.ber_sweep(code, G, config.R0, snrs, 200_000, dev, np.float32, seed=11)
+    for p64, p32 in zip(r64, r32):
+        n_ref, k_ref, it_ref = REFERENCE_R0_CCSDS[p64["es_n0_db"]]
+        lo, hi = clopper_pearson(k_ref, n_ref)
+        assert lo <= p64["fer"] <= hi, (p64["es_n0_db"], p64["fer"], lo, hi)
+        assert lo <= p32["fer"] <= hi
+        # mean iteration count: the reference charges failures max_iters, this build reports max-1
+        mean_it = (p64["iterations"] + p64["not_converged"]) / p64["frames"]
+        assert abs(mean_it - it_ref) < 0.5
+        # float32 against float64 on the same frames: same seed -> same LLRs
+        assert abs(p32["not_converged"] - p64["not_converged"]) <= 3 + 0.01 * p64["not_converged"]
+        assert p64["converged_wrong"] == 0
+    assert r64[0]["fer"] > r64[1]["fer"] > r64[2]["fer"] >= r64[3]["fer"]
