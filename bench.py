@@ -78,7 +78,8 @@ def timed_steps(fn, steps, warmup, torch, dist, world):
     wall = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)
     if world > 1:
-        t = torch.tensor([wall, dev_ms], dtype=torch.float64, device="cuda")
+        t = torch.tensor([wall, dev_ms], dtype=torch.float64,
+                         device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall, dev_ms = float(t[0]), float(t[1])
     return wall, dev_ms
@@ -110,9 +111,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the decoder has no CPU path")
+    # rehearsal on a one-GPU box: LDPC_BENCH_BACKEND=gloo puts every rank on device 0 and runs the
+    # collectives through host memory; the real multi-GPU run uses RCCL, one rank per GPU
+    backend = os.environ.get("LDPC_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     device = torch.device("cuda", local)
 
     from ldpc_amd import codes, config, sweep

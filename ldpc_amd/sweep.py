@@ -101,7 +101,12 @@ def allreduce_counters(counters: "torch.Tensor") -> "torch.Tensor":
     import torch.distributed as dist
 
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(counters, op=dist.ReduceOp.SUM)
+        if counters.is_cuda and dist.get_backend() != "nccl":   # host-memory backends (gloo rehearsals)
+            host = counters.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            counters.copy_(host)
+        else:
+            dist.all_reduce(counters, op=dist.ReduceOp.SUM)
     return counters
 
 
