@@ -1,9 +1,9 @@
 // Circulant (quasi-cyclic) flooding decoder: rules R0-R4, float or double.
 //
 // H is an mb x nb array of Z x Z circulant blocks.  A workgroup decodes F frames at once
-// ("slots"); thread tid = f*Z + z works on index z of slot f.  In the check-node phase thread
-// (f, z) owns check (br, z) of every block row br in turn, in the variable-node phase it owns
-// variable (bc, z) of every block column bc in turn.  The base graph (which block column and
+// ("slots"); a thread works on index z of slot f.  In the check-node phase thread (f, z) owns
+// check (br, z) of the block rows assigned to its wave, in the variable-node phase variable
+// (bc, z) of its wave's block columns (qc_map_thread below).  The base graph (which block column and
 // which shift each circulant has) is the same for every thread, so it is read through uniform
 // (scalar) loads and every loop bound is wave-uniform.
 //
@@ -28,11 +28,42 @@
 
 namespace ldpc {
 
+// The circulant tables are read through the constant address space: with a wave-uniform index the
+// compiler then issues scalar loads and unpacks the entries on the scalar unit.
+typedef const unsigned __attribute__((address_space(4))) *const_u32;
+typedef const int __attribute__((address_space(4))) *const_i32;
+__device__ __forceinline__ const_u32 as_const(const unsigned *p) { return (const_u32)(unsigned long long)p; }
+__device__ __forceinline__ const_i32 as_const(const int *p) { return (const_i32)(unsigned long long)p; }
+
 struct QcCtx {
     int Z, F, FZ, mb, nb;
-    int tid, fz0, z;  // fz0 = f*Z
+    int tid, fz0, z;  // tid = f*Z + z: position of this thread's (slot, z) pair in an [..][FZ] row; fz0 = f*Z
+    int w0, wstep;    // this wave takes block rows / block columns w0, w0 + wstep, ...
     bool lane_on;     // thread maps to a (slot, z) pair at all
 };
+
+// Thread mapping shared by the table-driven kernels.  A wave covers 64 consecutive z of one slot
+// (Z >= 64; a block row then spans ceil(Z/64) waves) or floor(64/Z) slots side by side (Z < 64).
+// W such wave sets work on one slot group at a time and split its block rows (check phase) and
+// block columns (variable phase) between them; G groups share a workgroup.  So every wave sees a
+// single block row per step (its degree and table entries are wave-uniform) and a frame of a code
+// with a small Z and a large base graph still spreads over many waves.
+__device__ __forceinline__ int qc_map_thread(QcCtx &x, int Z, int W)
+{
+    const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+    const int S = Z >= 64 ? 1 : 64 / Z, Zw = (Z + 63) / 64;
+    const int group = wave / (W * Zw), within = wave % (W * Zw);
+    const int s = Z >= 64 ? 0 : lane / Z;
+    x.w0 = within / Zw;
+    x.wstep = W;
+    x.z = Z >= 64 ? (within % Zw) * 64 + lane : lane - s * Z;
+    x.lane_on = Z >= 64 ? x.z < Z : s < S;
+    const int f = x.lane_on ? group * S + s : 0;
+    if (!x.lane_on) x.z = 0;
+    x.fz0 = f * Z;
+    x.tid = x.fz0 + x.z;
+    return f;
+}
 
 #define LDPC_SHIFT_MASK 0xfffu
 #define LDPC_PAIR_BIT 0x8000u
@@ -41,7 +72,7 @@ struct QcCtx {
 // check node of degree D for thread (f, z); returns the parity of the hard decisions (or, for the
 // R0 iteration-0 check on raw LLRs, whether the float row sum fails the "% 2 == 0" test).
 template <int RULE, typename T, int D>
-__device__ __forceinline__ int check_row(const QcCtx &x, const Cfg<T> &g, const unsigned *__restrict__ info,
+__device__ __forceinline__ int check_row(const QcCtx &x, const Cfg<T> &g, const_u32 info,
                                          int e0, T *msg, const T *post, const uint8_t *hb,
                                          bool want_syndrome, bool float_check, bool update)
 {
@@ -127,7 +158,7 @@ __device__ __forceinline__ int check_row(const QcCtx &x, const Cfg<T> &g, const 
 // ------------------------------------------------------------------------------------------
 // variable node of degree D for thread (f, z)
 template <int RULE, typename T, int D>
-__device__ __forceinline__ void var_col(const QcCtx &x, const Cfg<T> &g, const unsigned *__restrict__ info,
+__device__ __forceinline__ void var_col(const QcCtx &x, const Cfg<T> &g, const_u32 info,
                                         int k0, int bc, T *msg, const T *L, T *post, uint8_t *hb,
                                         bool want_post)
 {
@@ -198,12 +229,12 @@ __device__ __forceinline__ void var_col(const QcCtx &x, const Cfg<T> &g, const u
 #define LDPC_CASE_ROW(N)                                                                          \
     case N:                                                                                       \
         if constexpr (N <= DC)                                                                    \
-            bad |= check_row<RULE, T, N>(x, g, q.row_info, e0, msg, post, hb, want_syn, float_check, update); \
+            bad |= check_row<RULE, T, N>(x, g, as_const(q.row_info), e0, msg, post, hb, want_syn, float_check, update); \
         break;
 #define LDPC_CASE_COL(N)                                                                          \
     case N:                                                                                       \
         if constexpr (N <= DV)                                                                    \
-            var_col<RULE, T, N>(x, g, q.col_info, k0, bc, msg, L, post, hb, want_post);            \
+            var_col<RULE, T, N>(x, g, as_const(q.col_info), k0, bc, msg, L, post, hb, want_post);            \
         break;
 
 template <int RULE, typename T, int DC>
@@ -212,8 +243,8 @@ __device__ __forceinline__ int check_phase(const QcCtx &x, const Cfg<T> &g, cons
                                            bool float_check, bool update)
 {
     int bad = 0;
-    for (int br = 0; br < x.mb; ++br) {
-        const int e0 = q.row_ptr[br], d = q.row_ptr[br + 1] - e0;
+    for (int br = x.w0; br < x.mb; br += x.wstep) {
+        const int e0 = as_const(q.row_ptr)[br], d = as_const(q.row_ptr)[br + 1] - e0;
         switch (d) {
             LDPC_CASE_ROW(1) LDPC_CASE_ROW(2) LDPC_CASE_ROW(3) LDPC_CASE_ROW(4) LDPC_CASE_ROW(5)
             LDPC_CASE_ROW(6) LDPC_CASE_ROW(7) LDPC_CASE_ROW(8) LDPC_CASE_ROW(9) LDPC_CASE_ROW(10)
@@ -229,10 +260,10 @@ template <int RULE, typename T, int DV>
 __device__ __forceinline__ void var_phase(const QcCtx &x, const Cfg<T> &g, const QcDev &q, T *msg,
                                           const T *L, T *post, uint8_t *hb, bool want_post)
 {
-    for (int bc = 0; bc < x.nb; ++bc) {
-        const int k0 = q.col_ptr[bc], d = q.col_ptr[bc + 1] - k0;
+    for (int bc = x.w0; bc < x.nb; bc += x.wstep) {
+        const int k0 = as_const(q.col_ptr)[bc], d = as_const(q.col_ptr)[bc + 1] - k0;
         switch (d) {
-            case 0: var_col<RULE, T, 0>(x, g, q.col_info, k0, bc, msg, L, post, hb, want_post); break;
+            case 0: var_col<RULE, T, 0>(x, g, as_const(q.col_info), k0, bc, msg, L, post, hb, want_post); break;
             LDPC_CASE_COL(1) LDPC_CASE_COL(2) LDPC_CASE_COL(3) LDPC_CASE_COL(4) LDPC_CASE_COL(5)
             LDPC_CASE_COL(6) LDPC_CASE_COL(7) LDPC_CASE_COL(8) LDPC_CASE_COL(9) LDPC_CASE_COL(10)
             LDPC_CASE_COL(11) LDPC_CASE_COL(12) LDPC_CASE_COL(13) LDPC_CASE_COL(14) LDPC_CASE_COL(15)
@@ -247,18 +278,15 @@ __device__ __forceinline__ void var_phase(const QcCtx &x, const Cfg<T> &g, const
 
 // ------------------------------------------------------------------------------------------
 template <int RULE, typename T, typename TL, int DC, int DV>
-__global__ void __launch_bounds__(512) decode_qc_kernel(QcDev q, Cfg<T> g, int F, const TL *__restrict__ llr, long long frames,
+__global__ void __launch_bounds__(512) decode_qc_kernel(QcDev q, Cfg<T> g, int F, int W, const TL *__restrict__ llr, long long frames,
                                  uint8_t *__restrict__ hard_out, int *__restrict__ iters_out,
                                  uint8_t *__restrict__ conv_out, T *__restrict__ post_out)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     QcCtx x;
     x.Z = q.Z; x.F = F; x.FZ = F * q.Z; x.mb = q.mb; x.nb = q.nb;
-    x.tid = threadIdx.x;
-    x.lane_on = x.tid < x.FZ;
-    const int f = x.lane_on ? x.tid / x.Z : 0;
-    x.z = x.lane_on ? x.tid - f * x.Z : 0;
-    x.fz0 = f * x.Z;
+    const int f = qc_map_thread(x, q.Z, W);
+    const bool reporter = x.lane_on && x.z == 0 && x.w0 == 0;  // one thread per slot writes iters / converged
     const int n = q.nb * q.Z;
     const bool want_post = post_out != nullptr;
     const bool keep_post = RULE == 0 || want_post;
@@ -275,7 +303,7 @@ __global__ void __launch_bounds__(512) decode_qc_kernel(QcDev q, Cfg<T> g, int F
         const bool active = x.lane_on && frame < frames;
         // ---- channel LLRs in, messages initialised (ldpc.py:151-158, bpsk.py:170-196)
         if (x.lane_on) {
-            for (int bc = 0; bc < x.nb; ++bc) {
+            for (int bc = x.w0; bc < x.nb; bc += x.wstep) {
                 const int vi = bc * x.FZ + x.tid;
                 T l = active ? (T)llr[frame * n + bc * x.Z + x.z] : (T)0;
                 L[vi] = l;
@@ -283,10 +311,10 @@ __global__ void __launch_bounds__(512) decode_qc_kernel(QcDev q, Cfg<T> g, int F
                 if (RULE != 0) hb[vi] = (uint8_t)hard_bit<RULE>(l);
             }
         }
-        if (x.tid < F) slot_bad[x.tid] = 0;
+        if ((int)threadIdx.x < F) slot_bad[threadIdx.x] = 0;
         __syncthreads();
         if (RULE != 0 && x.lane_on) {
-            for (int br = 0; br < x.mb; ++br)
+            for (int br = x.w0; br < x.mb; br += x.wstep)
                 for (int e = q.row_ptr[br]; e < q.row_ptr[br + 1]; ++e) {
                     const unsigned w = q.row_info[e];
                     int col = x.z + (int)(w & LDPC_SHIFT_MASK);
@@ -310,7 +338,7 @@ __global__ void __launch_bounds__(512) decode_qc_kernel(QcDev q, Cfg<T> g, int F
             if (g.early_exit) {
                 if (!done && !slot_bad[f]) {
                     // ldpc.py:165-170: every parity check holds -> this frame is finished
-                    for (int bc = 0; bc < x.nb; ++bc) {
+                    for (int bc = x.w0; bc < x.nb; bc += x.wstep) {
                         const int vi = bc * x.FZ + x.tid;
                         uint8_t h;
                         if (RULE == 0) {
@@ -322,11 +350,11 @@ __global__ void __launch_bounds__(512) decode_qc_kernel(QcDev q, Cfg<T> g, int F
                         hard_out[frame * n + bc * x.Z + x.z] = h;
                         if (want_post) post_out[frame * n + bc * x.Z + x.z] = post[vi];
                     }
-                    if (x.z == 0) { iters_out[frame] = t; conv_out[frame] = 1; }
+                    if (reporter) { iters_out[frame] = t; conv_out[frame] = 1; }
                     done = true;
                 }
                 if (!__syncthreads_or(!done)) break;  // every slot of the workgroup has finished
-                if (x.tid < F) slot_bad[x.tid] = 0;
+                if ((int)threadIdx.x < F) slot_bad[threadIdx.x] = 0;
             }
             // ---- variable nodes
             if (!done) var_phase<RULE, T, DV>(x, g, q, msg, L, post, hb, want_post);
@@ -340,12 +368,12 @@ __global__ void __launch_bounds__(512) decode_qc_kernel(QcDev q, Cfg<T> g, int F
             __syncthreads();
         }
         if (!done) {
-            for (int bc = 0; bc < x.nb; ++bc) {
+            for (int bc = x.w0; bc < x.nb; bc += x.wstep) {
                 const int vi = bc * x.FZ + x.tid;
                 hard_out[frame * n + bc * x.Z + x.z] = RULE == 0 ? (uint8_t)hard_bit<0>(post[vi]) : hb[vi];
                 if (want_post) post_out[frame * n + bc * x.Z + x.z] = post[vi];
             }
-            if (x.z == 0) {
+            if (reporter) {
                 iters_out[frame] = g.early_exit ? g.max_iters - 1 : g.max_iters;
                 conv_out[frame] = g.early_exit ? 0 : (uint8_t)!slot_bad[f];
             }
@@ -380,18 +408,20 @@ static size_t qc_lds_bytes(const QcDev &q, int rule, int F, bool want_post)
     return b;
 }
 
-// frames per workgroup: fill whole waves with as little LDS as possible
-static int pick_slots(int Z, size_t bytes_per_slot)
+// Workgroup shape: G slot groups x W row-parallel wave sets x ceil(Z/64) waves, at most 8 waves.
+// Small frames: several groups (independent frames) per workgroup; large frames: one group whose
+// block rows / columns are split over up to 8 waves.
+struct QcShape { int F, W, threads; };
+static QcShape pick_shape(const QcDev &q, size_t bytes_per_slot)
 {
-    int best = 1;
-    double best_util = 0.0;
-    for (int F = 1; F <= 8; ++F) {
-        const int threads = ((F * Z + 63) / 64) * 64;
-        if (threads > 512 || (size_t)F * bytes_per_slot > kLdsLimit / 2) break;
-        const double util = (double)(F * Z) / threads;
-        if (util > best_util + 0.02) { best_util = util; best = F; }
-    }
-    return best;
+    const int S = q.Z >= 64 ? 1 : 64 / q.Z, Zw = (q.Z + 63) / 64;
+    int G = 1;
+    while (G < 4 && (size_t)(G + 1) * S * bytes_per_slot <= kLdsLimit / 2 && (G + 1) * Zw <= 8) ++G;
+    int W = 8 / (G * Zw);
+    if (W < 1) W = 1;
+    const int most = q.mb < q.nb ? q.mb : q.nb;
+    if (W > most) W = most;
+    return QcShape{G * S, W, G * W * Zw * 64};
 }
 
 template <int RULE, typename T, typename TL, int DC, int DV>
@@ -399,17 +429,15 @@ static hipError_t launch_qc_t(const QcDev &q, const ldpc_decode_config &cfg, con
                               int num_cus, const char **name, bool *supported)
 {
     const bool want_post = io.posterior != nullptr;
+    const int S = q.Z >= 64 ? 1 : 64 / q.Z;
     const size_t per_slot = qc_lds_bytes<T>(q, RULE, 1, want_post);
-    if (per_slot > kLdsLimit) { *supported = false; return hipSuccess; }
-    int F = pick_slots(q.Z, per_slot);
-    const char *force = getenv("LDPC_QC_SLOTS");
-    if (force && atoi(force) >= 1 && atoi(force) <= 16) F = atoi(force);
-    const size_t lds = qc_lds_bytes<T>(q, RULE, F, want_post);
-    const int threads = ((F * q.Z + 63) / 64) * 64;
-    if (lds > kLdsLimit || threads > 512) { *supported = false; return hipSuccess; }
+    const QcShape sh = pick_shape(q, per_slot);
+    const size_t lds = qc_lds_bytes<T>(q, RULE, sh.F, want_post);
+    if ((size_t)S * per_slot > kLdsLimit || lds > kLdsLimit || sh.threads > 512) { *supported = false; return hipSuccess; }
     *supported = true;
+    const int F = sh.F;
     size_t per_cu = kLdsLimit / lds;
-    const size_t wave_cap = 32 / (threads / 64);
+    const size_t wave_cap = 32 / (sh.threads / 64);
     if (per_cu > wave_cap) per_cu = wave_cap;
     if (per_cu < 1) per_cu = 1;
     const long long groups = (io.frames + F - 1) / F;
@@ -420,7 +448,7 @@ static hipError_t launch_qc_t(const QcDev &q, const ldpc_decode_config &cfg, con
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(threads), lds, io.stream, q, make_cfg<T>(cfg), F,
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(sh.threads), lds, io.stream, q, make_cfg<T>(cfg), F, sh.W,
                        reinterpret_cast<const TL *>(io.llr), io.frames, io.hard, io.iters,
                        io.converged, reinterpret_cast<T *>(io.posterior));
     *name = sizeof(T) == 8 ? "qc_f64" : "qc_f32";

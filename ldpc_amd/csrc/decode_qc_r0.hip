@@ -73,7 +73,8 @@ template <> struct Num<double> {
 
 struct R0Ctx {
     int Z, FZ, mb, nb;
-    int tid, fz0, z;
+    int tid, fz0, z;  // tid = f*Z + z, fz0 = f*Z
+    int w0, wstep;    // this wave takes block rows / block columns w0, w0 + wstep, ...
 };
 
 // rotated index inside the slot: (z + s) mod Z without a compare (unsigned wrap-around)
@@ -161,7 +162,7 @@ __device__ __forceinline__ int r0_check_phase(const R0Ctx &x, const_i32 row_ptr,
                                               const T *post, typename Num<T>::Pair *cs)
 {
     int bad = 0;
-    for (int br = 0; br < x.mb; ++br) {
+    for (int br = x.w0; br < x.mb; br += x.wstep) {
         const int e0 = row_ptr[br], d = row_ptr[br + 1] - e0;
         switch (d) {
             R0_CASE_ROW(1) R0_CASE_ROW(2) R0_CASE_ROW(3) R0_CASE_ROW(4) R0_CASE_ROW(5)
@@ -178,7 +179,7 @@ template <typename T, int DV>
 __device__ __forceinline__ void r0_var_phase(const R0Ctx &x, T scale, const_i32 col_ptr, const_u32 col_info,
                                              T *post, const T *L, const typename Num<T>::Pair *cs)
 {
-    for (int bc = 0; bc < x.nb; ++bc) {
+    for (int bc = x.w0; bc < x.nb; bc += x.wstep) {
         const int k0 = col_ptr[bc], d = col_ptr[bc + 1] - k0;
         switch (d) {
             case 0: r0_var<T, 0>(x, scale, col_info, k0, bc, post, L, cs); break;
@@ -197,7 +198,7 @@ __device__ __forceinline__ void r0_var_phase(const R0Ctx &x, T scale, const_i32 
 // ------------------------------------------------------------------------------------------
 template <typename T, typename TL, int DC, int DV>
 __global__ void __launch_bounds__(512)
-decode_qc_r0_kernel(QcDev q, Cfg<T> g, int F, const TL *__restrict__ llr, long long frames,
+decode_qc_r0_kernel(QcDev q, Cfg<T> g, int F, int W, const TL *__restrict__ llr, long long frames,
                     uint8_t *__restrict__ hard_out, int *__restrict__ iters_out,
                     uint8_t *__restrict__ conv_out, T *__restrict__ post_out)
 {
@@ -205,12 +206,21 @@ decode_qc_r0_kernel(QcDev q, Cfg<T> g, int F, const TL *__restrict__ llr, long l
     typedef typename Num<T>::Pair Pair;
     R0Ctx x;
     x.Z = q.Z; x.FZ = F * q.Z; x.mb = q.mb; x.nb = q.nb;
-    x.tid = threadIdx.x;
-    const bool lane_on = x.tid < x.FZ;
-    const int f = lane_on ? x.tid / x.Z : 0;
-    x.z = lane_on ? x.tid - f * x.Z : 0;
+    // thread mapping as in decode_qc.hip: a wave covers 64 z of one slot (or 64/Z slots side by side),
+    // W wave sets split the block rows / columns of a slot group, G groups share the workgroup
+    const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+    const int S = q.Z >= 64 ? 1 : 64 / q.Z, Zw = (q.Z + 63) / 64;
+    const int group = wave / (W * Zw), within = wave % (W * Zw);
+    const int sub = q.Z >= 64 ? 0 : lane / q.Z;
+    x.w0 = within / Zw;
+    x.wstep = W;
+    x.z = q.Z >= 64 ? (within % Zw) * 64 + lane : lane - sub * q.Z;
+    const bool lane_on = q.Z >= 64 ? x.z < q.Z : sub < S;
+    const int f = lane_on ? group * S + sub : 0;
+    if (!lane_on) x.z = 0;
     x.fz0 = f * x.Z;
-    if (!lane_on) x.tid = 0;
+    x.tid = x.fz0 + x.z;
+    const bool reporter = lane_on && x.z == 0 && x.w0 == 0;
     const int n = q.nb * q.Z;
     const const_i32 row_ptr = as_const(q.row_ptr), col_ptr = as_const(q.col_ptr);
     const const_u32 row_info = as_const(q.row_info), col_info = as_const(q.colr_info);
@@ -225,7 +235,7 @@ decode_qc_r0_kernel(QcDev q, Cfg<T> g, int F, const TL *__restrict__ llr, long l
         const long long frame = grp * F + f;
         const bool active = lane_on && frame < frames;
         if (lane_on) {
-            for (int bc = 0; bc < x.nb; ++bc) {
+            for (int bc = x.w0; bc < x.nb; bc += x.wstep) {
                 const int vi = bc * x.FZ + x.tid;
                 const T l = (active ? (T)llr[frame * n + bc * x.Z + x.z] : (T)0) + (T)0;  // -0.0 -> +0.0
                 L[vi] = l;
@@ -247,13 +257,13 @@ decode_qc_r0_kernel(QcDev q, Cfg<T> g, int F, const TL *__restrict__ llr, long l
             __syncthreads();
             if (g.early_exit) {
                 if (!done && !slot_bad[f]) {  // ldpc.py:165-170
-                    for (int bc = 0; bc < x.nb; ++bc) {
+                    for (int bc = x.w0; bc < x.nb; bc += x.wstep) {
                         const T v = post[bc * x.FZ + x.tid];
                         hard_out[frame * n + bc * x.Z + x.z] =
                             float_check ? (v == (T)0 ? 0 : (v == (T)1 ? 1 : 2)) : (uint8_t)hard_bit<0>(v);
                         if (post_out) post_out[frame * n + bc * x.Z + x.z] = v;
                     }
-                    if (x.z == 0) { iters_out[frame] = t; conv_out[frame] = 1; }
+                    if (reporter) { iters_out[frame] = t; conv_out[frame] = 1; }
                     done = true;
                 }
                 if (!__syncthreads_or(!done)) break;
@@ -269,12 +279,12 @@ decode_qc_r0_kernel(QcDev q, Cfg<T> g, int F, const TL *__restrict__ llr, long l
             __syncthreads();
         }
         if (!done) {  // ldpc.py:210-227
-            for (int bc = 0; bc < x.nb; ++bc) {
+            for (int bc = x.w0; bc < x.nb; bc += x.wstep) {
                 const T v = post[bc * x.FZ + x.tid];
                 hard_out[frame * n + bc * x.Z + x.z] = (uint8_t)hard_bit<0>(v);
                 if (post_out) post_out[frame * n + bc * x.Z + x.z] = v;
             }
-            if (x.z == 0) {
+            if (reporter) {
                 iters_out[frame] = g.early_exit ? g.max_iters - 1 : g.max_iters;
                 conv_out[frame] = g.early_exit ? 0 : (uint8_t)!slot_bad[f];
             }
@@ -293,34 +303,32 @@ static size_t r0_lds_bytes(const QcDev &q, int F)
     return (size_t)q.mb * FZ * 2 * sizeof(T) + (size_t)q.nb * FZ * 2 * sizeof(T) + (size_t)F * sizeof(int) + 16;
 }
 
-static int pick_slots(int Z, size_t bytes_per_slot)
+struct R0Shape { int F, W, threads; };
+static R0Shape pick_shape(const QcDev &q, size_t bytes_per_slot)
 {
-    int best = 1;
-    double best_util = 0.0;
-    for (int F = 1; F <= 8; ++F) {
-        const int threads = ((F * Z + 63) / 64) * 64;
-        if (threads > 512 || (size_t)F * bytes_per_slot > kLdsLimit / 2) break;
-        const double util = (double)(F * Z) / threads;
-        if (util > best_util + 0.02) { best_util = util; best = F; }
-    }
-    return best;
+    const int S = q.Z >= 64 ? 1 : 64 / q.Z, Zw = (q.Z + 63) / 64;
+    int G = 1;
+    while (G < 4 && (size_t)(G + 1) * S * bytes_per_slot <= kLdsLimit / 2 && (G + 1) * Zw <= 8) ++G;
+    int W = 8 / (G * Zw);
+    if (W < 1) W = 1;
+    const int most = q.mb < q.nb ? q.mb : q.nb;
+    if (W > most) W = most;
+    return R0Shape{G * S, W, G * W * Zw * 64};
 }
 
 template <typename T, typename TL, int DC, int DV>
 static hipError_t launch_r0_t(const QcDev &q, const ldpc_decode_config &cfg, const Launch &io,
                               int num_cus, const char **name, bool *supported)
 {
+    const int S = q.Z >= 64 ? 1 : 64 / q.Z;
     const size_t per_slot = r0_lds_bytes<T>(q, 1);
-    if (per_slot > kLdsLimit) { *supported = false; return hipSuccess; }
-    int F = pick_slots(q.Z, per_slot);
-    const char *force = getenv("LDPC_QC_SLOTS");
-    if (force && atoi(force) >= 1 && atoi(force) <= 16) F = atoi(force);
-    const size_t lds = r0_lds_bytes<T>(q, F);
-    const int threads = ((F * q.Z + 63) / 64) * 64;
-    if (lds > kLdsLimit || threads > 512) { *supported = false; return hipSuccess; }
+    const R0Shape sh = pick_shape(q, per_slot);
+    const size_t lds = r0_lds_bytes<T>(q, sh.F);
+    if ((size_t)S * per_slot > kLdsLimit || lds > kLdsLimit || sh.threads > 512) { *supported = false; return hipSuccess; }
     *supported = true;
+    const int F = sh.F;
     size_t per_cu = kLdsLimit / lds;
-    const size_t wave_cap = 32 / (threads / 64);
+    const size_t wave_cap = 32 / (sh.threads / 64);
     if (per_cu > wave_cap) per_cu = wave_cap;
     if (per_cu < 1) per_cu = 1;
     const long long groups = (io.frames + F - 1) / F;
@@ -335,7 +343,7 @@ static hipError_t launch_r0_t(const QcDev &q, const ldpc_decode_config &cfg, con
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(threads), lds, io.stream, q, g, F,
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(sh.threads), lds, io.stream, q, g, F, sh.W,
                        reinterpret_cast<const TL *>(io.llr), io.frames, io.hard, io.iters,
                        io.converged, reinterpret_cast<T *>(io.posterior));
     *name = sizeof(T) == 8 ? "qc_r0_f64" : "qc_r0_f32";
