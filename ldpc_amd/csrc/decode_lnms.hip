@@ -1,0 +1,483 @@
+// Row-layered normalised min-sum (build extension, see LDPC_RULE_LNMS in ldpc_amd.h), specialised
+// at compile time for the packaged circulant codes.
+//
+// One layer = one block row.  Thread (f, z) owns check (br, z) of every block row of frame slot f.
+// What is kept where:
+//   * posteriors P of the variables that take part in two or more checks: LDS, [column][Z];
+//   * variables of degree one ("private" to their only check, e.g. the extension parity bits of the
+//     NR base graphs): never stored.  Such a variable always sends its channel LLR, which is
+//     fetched from the LLR array one layer ahead, and its posterior L + r is rebuilt from the
+//     check's state when hard decisions are needed;
+//   * the previous messages of a check, compressed to three words: A = scale * m1, B = scale * m2
+//     (smallest / second smallest input magnitude) and W = position of the smallest input (bits
+//     24-28) | sign parity of the inputs (bit 31) | sign of each input (low bits, first edge
+//     highest).  The first RL block rows keep them in registers, the others in LDS.
+// A layer reads P (rotated), subtracts the old message, updates (m1, m2, signs), adds the new
+// message and writes P back to the same place.  All checks of a block row touch distinct
+// variables (blocks that are sums of two circulants are not supported), so the block-parallel
+// update equals a check-by-check sweep bit for bit.  Workgroups of more than one wave need a
+// barrier only between layers that share a block column; consecutive layers on disjoint columns
+// run back to back.
+//
+// NR BG1 Z = 384 in float: 39 KiB of posteriors + 40.5 KiB of check state in LDS and 111 state
+// registers per thread, two workgroups (frames) per compute unit.
+#include <cstdio>
+#include <cstdlib>
+
+#include "spec_common.h"
+
+namespace ldpc {
+
+template <class C>
+struct LnPlan {
+    static constexpr int cdeg(int bc) { return C::col_ptr[bc + 1] - C::col_ptr[bc]; }
+    static constexpr int rdeg(int br) { return C::row_ptr[br + 1] - C::row_ptr[br]; }
+    static constexpr bool has_pairs()
+    {
+        for (int k = 0; k < C::EB; ++k) if (C::col_pair[k]) return true;
+        return false;
+    }
+    // position inside block row br of its degree-one column, -1 if it has none
+    static constexpr int priv_pos(int br)
+    {
+        int pos = -1;
+        for (int e = C::row_ptr[br]; e < C::row_ptr[br + 1]; ++e)
+            if (cdeg(C::row_col[e]) == 1) pos = e - C::row_ptr[br];
+        return pos;
+    }
+    static constexpr int priv_count(int br)
+    {
+        int c = 0;
+        for (int e = C::row_ptr[br]; e < C::row_ptr[br + 1]; ++e) c += cdeg(C::row_col[e]) == 1;
+        return c;
+    }
+    static constexpr bool supported()
+    {
+        if (has_pairs() || C::MAX_DC > 24) return false;  // sign bits and argmin position share one word
+        int layers = 0;
+        for (int br = 0; br < C::MB; ++br) {
+            if (priv_count(br) > 1) return false;
+            layers += rdeg(br) >= 2;
+        }
+        return layers > 0;
+    }
+    static constexpr bool shared(int bc) { return cdeg(bc) >= 2; }
+    static constexpr int lds_index(int bc)
+    {
+        int k = 0;
+        for (int c = 0; c < bc; ++c) k += shared(c);
+        return k;
+    }
+    static constexpr int NS = lds_index(C::NB);
+    // does layer br touch a shared column that an earlier layer since the last barrier touched?
+    // (the first layer of a sweep always synchronises with whatever ran before the sweep)
+    static constexpr bool barrier_before(int br)
+    {
+        bool used[C::NB] = {};
+        bool first = true;
+        for (int r = 0; r <= br; ++r) {
+            if (rdeg(r) < 2) continue;
+            bool clash = first;
+            for (int e = C::row_ptr[r]; e < C::row_ptr[r + 1]; ++e)
+                if (shared(C::row_col[e]) && used[C::row_col[e]]) clash = true;
+            if (clash) for (int c = 0; c < C::NB; ++c) used[c] = false;
+            for (int e = C::row_ptr[r]; e < C::row_ptr[r + 1]; ++e) used[C::row_col[e]] = true;
+            first = false;
+            if (r == br) return clash;
+        }
+        return false;
+    }
+    static constexpr bool is_priv_layer(int br) { return rdeg(br) >= 2 && priv_pos(br) >= 0; }
+    // the next layer after br (cyclically) that has a private variable; -1 if there is none
+    static constexpr int next_priv_layer(int br)
+    {
+        for (int k = 1; k <= C::MB; ++k) {
+            const int r = (br + k) % C::MB;
+            if (is_priv_layer(r)) return r;
+        }
+        return -1;
+    }
+    static constexpr int first_priv_layer() { return next_priv_layer(C::MB - 1); }
+    static constexpr int barriers_per_sweep()
+    {
+        int c = 0;
+        for (int br = 0; br < C::MB; ++br) c += rdeg(br) >= 2 && barrier_before(br);
+        return c;
+    }
+};
+
+template <class C, typename T, int F, int RL>
+struct LnLayout {
+    typedef LnPlan<C> PL;
+    static constexpr int ST = sizeof(T);
+    static constexpr int THREADS = ((F * C::Z + 63) / 64) * 64;
+    static constexpr bool SINGLE = THREADS == 64;
+    static constexpr int P_BYTES = ((PL::NS * C::Z * ST + 15) / 16) * 16;
+    static constexpr int LAYER_BYTES = C::Z * (2 * ST + 4);  // A[Z], B[Z], W[Z] of one spilled block row
+    static constexpr int ST_BYTES = (C::MB - RL) * LAYER_BYTES;
+    static constexpr int SLOT_BYTES = ((P_BYTES + ST_BYTES + 127) / 128) * 128 + (F > 1 ? 32 : 0);
+    static constexpr int FLAG_OFF = F * SLOT_BYTES;
+    static constexpr int LDS_BYTES = FLAG_OFF + 64;
+    // rotated offsets from one packed add and one 16-bit minimum: needs 2 * Z * ST and the
+    // posterior area below 64 KiB
+    static constexpr bool PACKED_ROT = !is_pow2(C::Z) && 2 * C::Z * ST <= 65535 && P_BYTES <= 65535;
+};
+
+// offset of element ((z + S) mod Z); zz = zb | ((zb - Z * ST) mod 2^16) << 16.  Adding S * ST to
+// both halves at once gives the unwrapped and the wrapped candidate; the smaller one (as
+// unsigned 16-bit numbers) is the answer.
+template <int Z, int ST, int S, bool PACKED>
+__device__ __forceinline__ unsigned ln_rot(unsigned zb, unsigned zz)
+{
+    if constexpr (S == 0) return zb;
+    else if constexpr (!PACKED) return rot_fwd<Z, ST, S>(zb);
+    else {
+        const unsigned t = zz + (unsigned)(S * ST) * 0x10001u;
+        unsigned a;
+        asm("v_min_u32_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1"
+            : "=v"(a) : "v"(t));
+        return a;
+    }
+}
+
+// LDS accesses by absolute byte address.  The kernels below have no static LDS, so the dynamic
+// segment starts at address 0 (the launcher checks that); with plain integers as addresses every
+// constant part of an offset ends up in the instruction's immediate field.
+template <typename T>
+__device__ __forceinline__ T lds_get(unsigned addr)
+{
+    return *reinterpret_cast<const __attribute__((address_space(3))) T *>((unsigned long long)addr);
+}
+template <typename T>
+__device__ __forceinline__ void lds_put(unsigned addr, T v)
+{
+    *reinterpret_cast<__attribute__((address_space(3))) T *>((unsigned long long)addr) = v;
+}
+
+template <class C, typename T, typename TL, int F, int RL, int WPE>
+__global__ void __launch_bounds__((LnLayout<C, T, F, RL>::THREADS)) __attribute__((amdgpu_waves_per_eu(WPE, 8)))
+lnms_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__restrict__ hard_out,
+            int *__restrict__ iters_out, uint8_t *__restrict__ conv_out, T *__restrict__ post_out)
+{
+    typedef LnPlan<C> PL;
+    typedef LnLayout<C, T, F, RL> LY;
+    static_assert(PL::supported(), "code shape not supported by the layered kernel");
+    constexpr int Z = C::Z, NB = C::NB, MB = C::MB, ST = sizeof(T);
+    constexpr int n = NB * Z;
+    constexpr bool PK = LY::PACKED_ROT;
+    extern __shared__ __align__(16) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const bool lane_on = tid < F * Z;
+    const int f = (F == 1 || !lane_on) ? 0 : tid / Z;
+    const int z = lane_on ? tid - f * Z : 0;
+    const unsigned P_b = (unsigned)f * LY::SLOT_BYTES;               // [NS][Z] T, absolute LDS address
+    const unsigned stA = P_b + LY::P_BYTES + (unsigned)z * ST;       // spilled check state of this thread
+    const unsigned stW = P_b + LY::P_BYTES + 2 * Z * ST + (unsigned)z * 4;
+    int *slot_bad = reinterpret_cast<int *>(smem + LY::FLAG_OFF);
+    const unsigned zb = (unsigned)z * ST;
+    const unsigned zz = zb | (((zb - (unsigned)(Z * ST)) & 0xffffu) << 16);
+    const unsigned long long slot_mask = (Z >= 64 ? ~0ull : ((1ull << (Z & 63)) - 1ull)) << ((f * Z) & 63);
+
+    const long long groups = (frames + F - 1) / F;
+    for (long long grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+        const long long frame = F == 1 ? grp : grp * F + f;
+        const bool active = lane_on && frame < frames;
+        // loads never depend on `active`: idle lanes read a frame that exists
+        const TL *__restrict__ lf = llr + (frame < frames ? frame : frames - 1) * n;
+
+        T A[RL > 0 ? RL : 1], B[RL > 0 ? RL : 1];
+        unsigned W[RL > 0 ? RL : 1];
+        static_for<0, MB>([&](auto br) {
+            if constexpr (br < RL) { A[br] = (T)0; B[br] = (T)0; W[br] = 0u; }
+            else if (lane_on) {
+                lds_put<T>(stA + (br - RL) * LY::LAYER_BYTES, (T)0);
+                lds_put<T>(stA + (br - RL) * LY::LAYER_BYTES + Z * ST, (T)0);
+                lds_put<unsigned>(stW + (br - RL) * LY::LAYER_BYTES, 0u);
+            }
+        });
+        static_for<0, NB>([&](auto bc) {
+            if constexpr (PL::shared(bc)) {
+                const T l = (T)lf[bc * Z + z] + (T)0;  // -0.0 -> +0.0: "negative" is "sign bit set" from here on
+                if (lane_on) lds_put<T>(P_b + PL::lds_index(bc) * Z * ST + zb, l);  // idle lanes alias lane 0
+            }
+        });
+        if constexpr (!LY::SINGLE) {
+            if (tid < F) slot_bad[tid] = 0;
+            __syncthreads();
+        }
+
+        auto load_state = [&](auto br, T &a, T &b, unsigned &w) {
+            if constexpr (br < RL) { a = A[br]; b = B[br]; w = W[br]; }
+            else {
+                a = lds_get<T>(stA + (br - RL) * LY::LAYER_BYTES);
+                b = lds_get<T>(stA + (br - RL) * LY::LAYER_BYTES + Z * ST);
+                w = lds_get<unsigned>(stW + (br - RL) * LY::LAYER_BYTES);
+            }
+        };
+        // index inside the frame, and channel LLR, of the private variable of block row br
+        auto priv_index = [&](auto br) -> int {
+            constexpr int e = C::row_ptr[br] + PL::priv_pos(br), bc = C::row_col[e], s = C::row_shift[e];
+            int zo = z;
+            asm volatile("" : "+v"(zo));  // one address per block row, computed where it is used
+            if constexpr (s == 0) return bc * Z + zo;
+            else { const int v = zo + s; return bc * Z + (v >= Z ? v - Z : v); }
+        };
+        auto load_priv = [&](auto br) -> T { return (T)lf[priv_index(br)] + (T)0; };
+        // posterior L + r of that variable, r rebuilt from the check's state
+        auto priv_value = [&](auto br) -> T {
+            constexpr int D = PL::rdeg(br), p = PL::priv_pos(br);
+            const T l = load_priv(br);
+            if constexpr (D < 2) return l;
+            else {
+                T a, b;
+                unsigned w;
+                load_state(br, a, b, w);
+                const T mag = (int)((w >> 24) & 31u) == p ? b : a;
+                return l + SNum<T>::flip_sign(mag, ((w << (31 - (D - 1 - p))) ^ w) & 0x80000000u);
+            }
+        };
+        auto write_out = [&](int iters, int conv) {
+            static_for<0, NB>([&](auto bc) {
+                if constexpr (PL::cdeg(bc) != 1) {
+                    T v;
+                    if constexpr (PL::shared(bc)) v = lds_get<T>(P_b + PL::lds_index(bc) * Z * ST + zb);
+                    else v = (T)lf[bc * Z + z] + (T)0;  // in no check at all: the channel decides
+                    hard_out[frame * n + bc * Z + z] = (uint8_t)hard_bit<1>(v);
+                    if (post_out) post_out[frame * n + bc * Z + z] = v;
+                }
+            });
+            static_for<0, MB>([&](auto br) {
+                if constexpr (PL::priv_pos(br) >= 0) {
+                    const T v = priv_value(br);
+                    const int i = priv_index(br);
+                    hard_out[frame * n + i] = (uint8_t)hard_bit<1>(v);
+                    if (post_out) post_out[frame * n + i] = v;
+                }
+            });
+            if (z == 0) { iters_out[frame] = iters; conv_out[frame] = (uint8_t)conv; }
+        };
+
+        T lp_cur = (T)0;  // channel LLR of the next private variable the sweep will need
+        if constexpr (PL::first_priv_layer() >= 0) lp_cur = load_priv(IC<(PL::first_priv_layer() >= 0 ? PL::first_priv_layer() : 0)>{});
+
+        bool done = !active;
+        for (int t = 0;; ++t) {
+            const bool last = t == g.max_iters;
+            if (g.early_exit || last) {
+                // ---- syndrome of the hard decisions `0 if P > 0 else 1` of the current posteriors
+                if constexpr (!LY::SINGLE) __syncthreads();
+                unsigned bad = 0;
+                if (!done && !(last && g.early_exit)) {
+                    static_for<0, MB>([&](auto br) {
+                        constexpr int e0 = C::row_ptr[br], D = C::row_ptr[br + 1] - e0, PP = PL::priv_pos(br);
+                        unsigned par = 0;
+                        unsigned zl = zb, zzl = zz;
+                        asm volatile("" : "+v"(zl), "+v"(zzl));  // keep the rotated addresses out of loop-invariant hoisting
+                        static_for<0, D>([&](auto p) {
+                            if constexpr (p == PP) par ^= hard_bit<1>(priv_value(br));
+                            else {
+                                constexpr int bc = C::row_col[e0 + p], s = C::row_shift[e0 + p];
+                                const T v = lds_get<T>(P_b + PL::lds_index(bc) * Z * ST + ln_rot<Z, ST, s, PK>(zl, zzl));
+                                par ^= hard_bit<1>(v);
+                            }
+                        });
+                        bad |= par;
+                    });
+                }
+                bool slot_ok, any_bad = false;
+                if constexpr (LY::SINGLE) {
+                    slot_ok = (__ballot(bad != 0) & slot_mask) == 0ull;
+                } else {
+                    if (bad) slot_bad[f] = 1;
+                    __syncthreads();
+                    slot_ok = slot_bad[f] == 0;
+                    static_for<0, F>([&](auto ff) { any_bad |= slot_bad[ff] != 0; });
+                }
+                if (last) {
+                    if (!done) write_out(g.early_exit ? g.max_iters - 1 : g.max_iters, g.early_exit ? 0 : (slot_ok ? 1 : 0));
+                    break;
+                }
+                if (!done && slot_ok) { write_out(t, 1); done = true; }
+                if constexpr (LY::SINGLE) {
+                    if (__ballot(!done) == 0ull) break;
+                } else {
+                    if (!any_bad) break;  // every slot that was still running has just converged
+                    __syncthreads();
+                    if (tid < F) slot_bad[tid] = 0;
+                }
+            }
+            // ---- one sweep over the layers
+            static_for<0, MB>([&](auto br) {
+                constexpr int e0 = C::row_ptr[br], D = C::row_ptr[br + 1] - e0, PP = PL::priv_pos(br);
+                if constexpr (D >= 2) {
+                    if constexpr (!LY::SINGLE && PL::barrier_before(br)) __syncthreads();
+                    T lp = (T)0;
+                    if constexpr (PP >= 0) {
+                        lp = lp_cur;
+                        constexpr int nx = PL::next_priv_layer(br);
+                        if constexpr (nx != br) lp_cur = load_priv(IC<nx>{});
+                    }
+                    if (!done) {
+                        T q[D];
+                        unsigned off[D];
+                        T Ao, Bo;
+                        unsigned w;
+                        load_state(br, Ao, Bo, w);
+                        const int idx_old = (int)((w >> 24) & 31u);
+                        const unsigned wp = w ^ (unsigned)((int)w >> 31);  // bit D-1-p: sign of the old message on edge p
+                        T m1 = Lim<T>::inf(), m2 = Lim<T>::inf();
+                        unsigned sq = 0;
+                        unsigned zl = zb, zzl = zz;
+                        asm volatile("" : "+v"(zl), "+v"(zzl));  // as above: hundreds of hoisted addresses would spill
+                        static_for<0, D>([&](auto p) {
+                            if constexpr (p == PP) {
+                                q[p] = lp;  // a variable of degree one always sends its channel LLR
+                                off[p] = 0;
+                            } else {
+                                constexpr int bc = C::row_col[e0 + p], s = C::row_shift[e0 + p];
+                                off[p] = P_b + ln_rot<Z, ST, s, PK>(zl, zzl) + PL::lds_index(bc) * Z * ST;
+                                const T v = lds_get<T>(off[p]);
+                                // previous message of this edge: magnitude B for the old argmin, else A
+                                const T mag = idx_old == p ? Bo : Ao;
+                                q[p] = v - SNum<T>::with_sign(mag, wp << (31 - (D - 1 - p)));
+                            }
+                            m2 = SNum<T>::second(m1, m2, q[p]);
+                            m1 = SNum<T>::min_abs(m1, q[p]);
+                            sq = (sq << 1) | (SNum<T>::sign_word(q[p]) >> 31);
+                        });
+                        const unsigned px = (unsigned)__popc(sq) << 31;  // sign parity of the inputs
+                        const T An = g.scale * m1, Bn = g.scale * m2;
+                        int idx = 0;
+                        static_for<0, D>([&](auto pp) {
+                            constexpr int p = D - 1 - pp;  // descending: the first minimum wins
+                            const bool ismin = t_abs(q[p]) == m1;
+                            idx = ismin ? p : idx;
+                            if constexpr (p != PP) {
+                                const T r = SNum<T>::flip_sign(ismin ? Bn : An, (px ^ SNum<T>::sign_word(q[p])) & 0x80000000u);
+                                lds_put<T>(off[p], q[p] + r);
+                            }
+                        });
+                        const unsigned wn = sq | ((unsigned)idx << 24) | px;
+                        if constexpr (br < RL) { A[br] = An; B[br] = Bn; W[br] = wn; }
+                        else {
+                            lds_put<T>(stA + (br - RL) * LY::LAYER_BYTES, An);
+                            lds_put<T>(stA + (br - RL) * LY::LAYER_BYTES + Z * ST, Bn);
+                            lds_put<unsigned>(stW + (br - RL) * LY::LAYER_BYTES, wn);
+                        }
+                    }
+                }
+            });
+        }
+        if constexpr (!LY::SINGLE) __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------ host
+// How many block rows keep their state in registers, and the occupancy the register allocator is
+// asked for.  A workgroup of four or more waves is planned as the only one on its compute unit
+// (its waves per SIMD fix the register budget); smaller workgroups are planned for three waves
+// per SIMD.  About 57 registers are left for everything that is not check state.
+template <class C, typename T, int F>
+struct LnConfig {
+    static constexpr int RPL = 2 * (int)sizeof(T) / 4 + 1;  // registers per block row
+    static constexpr int WAVES = ((F * C::Z + 63) / 64);
+    static constexpr int WPE = WAVES >= 4 ? (WAVES + 3) / 4 : 3;
+    static constexpr int VGPRS = WPE <= 2 ? 256 : (512 / WPE) / 8 * 8;
+    static constexpr int STATE_REGS = VGPRS - 57 > 180 ? 180 : VGPRS - 57;
+    static constexpr int RL = STATE_REGS <= 0 ? 0 : (C::MB < STATE_REGS / RPL ? C::MB : STATE_REGS / RPL);
+    static constexpr bool OK = WPE <= 4 && LnLayout<C, T, F, RL>::LDS_BYTES <= 160 * 1024;
+};
+// Frames per workgroup: the packaged default, doubled when that makes the number of waves a
+// multiple of the four SIMDs (waves of one workgroup are dealt round-robin to the SIMDs, and six
+// waves would leave two SIMDs with twice the work of the others).
+template <class C, typename T, int F>
+struct LnSlots {
+    static constexpr int W1 = (F * C::Z + 63) / 64, W2 = (2 * F * C::Z + 63) / 64;
+    static constexpr bool DOUBLE = W1 >= 4 && W1 % 4 != 0 && W2 % 4 == 0 && LnConfig<C, T, 2 * F>::OK;
+    static constexpr int value = DOUBLE ? 2 * F : F;
+};
+
+template <class C, typename T, typename TL, int F>
+static hipError_t launch_lnms(const ldpc_decode_config &cfg, const Launch &io, int num_cus, const char **name)
+{
+    typedef LnConfig<C, T, F> CF;
+    typedef LnLayout<C, T, F, CF::RL> LY;
+    Cfg<T> g;
+    g.rule = LDPC_RULE_LNMS; g.max_iters = cfg.max_iters; g.early_exit = cfg.early_exit;
+    g.float_syndrome0 = 0; g.num_active_checks = -1; g.num_refresh_vars = -1;
+    g.scale = (T)cfg.scale; g.clip_tanh_arg = (T)0; g.clip_prod = (T)0; g.clip_post = (T)0;
+    auto k = lnms_kernel<C, T, TL, F, CF::RL, CF::WPE>;
+    static int static_lds = -1;  // the kernel addresses LDS from 0: it must own the whole segment
+    if (static_lds < 0) {
+        hipFuncAttributes attr;
+        hipError_t ea = hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(k));
+        if (ea != hipSuccess) return ea;
+        static_lds = (int)attr.sharedSizeBytes;
+    }
+    if (static_lds != 0) return hipErrorInvalidConfiguration;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LY::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    static int per_cu = 0;  // resident workgroups per compute unit, as the runtime computes it
+    if (per_cu == 0) {
+        int nb = 0;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(k), LY::THREADS, LY::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        per_cu = nb < 1 ? 1 : nb;
+        if (getenv("LDPC_DEBUG_OCCUPANCY"))
+            fprintf(stderr, "lnms_kernel<%s,%d-byte>: %d frames per workgroup, %d block rows in registers, "
+                    "%d workgroups of %d threads per CU, %d B LDS each\n",
+                    C::name, (int)sizeof(T), F, CF::RL, per_cu, LY::THREADS, LY::LDS_BYTES);
+    }
+    const long long groups = (io.frames + F - 1) / F;
+    long long grid = (long long)num_cus * (long long)per_cu * 2;
+    if (grid > groups) grid = groups;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(LY::THREADS), LY::LDS_BYTES, io.stream, g,
+                       reinterpret_cast<const TL *>(io.llr), io.frames, io.hard, io.iters, io.converged,
+                       reinterpret_cast<T *>(io.posterior));
+    *name = sizeof(T) == 8 ? "spec_lnms_f64" : "spec_lnms_f32";
+    return hipGetLastError();
+}
+
+template <class C, int F>
+static hipError_t launch_lnms_code(const ldpc_decode_config &cfg, int compute_dtype, const Launch &io,
+                                   int num_cus, const char **name, bool *supported)
+{
+    *supported = true;
+    if constexpr (LnPlan<C>::supported()) {
+        constexpr int FD = LnSlots<C, double, F>::value, FS = LnSlots<C, float, F>::value;
+        if constexpr (LnConfig<C, double, FD>::OK) {
+            if (compute_dtype == LDPC_F64) {
+                if (io.llr_dtype == LDPC_F64) return launch_lnms<C, double, double, FD>(cfg, io, num_cus, name);
+                return launch_lnms<C, double, float, FD>(cfg, io, num_cus, name);
+            }
+        }
+        if constexpr (LnConfig<C, float, FS>::OK) {
+            if (compute_dtype == LDPC_F32 && io.llr_dtype == LDPC_F32)
+                return launch_lnms<C, float, float, FS>(cfg, io, num_cus, name);
+        }
+    }
+    *supported = false;
+    return hipSuccess;
+}
+
+hipError_t launch_spec_lnms(int spec_id, const ldpc_decode_config &cfg, int compute_dtype, const Launch &io,
+                            int num_cus, const char **name, bool *supported)
+{
+#ifdef LDPC_LNMS_DEV_ONLY  // development aid: instantiate one code only
+    return launch_lnms_code<LDPC_LNMS_DEV_ONLY, 1>(cfg, compute_dtype, io, num_cus, name, supported);
+#else
+    int id = 0;
+#define LDPC_LAUNCH(CODE, SLOTS)                                                                   \
+    if (spec_id == id) return launch_lnms_code<CODE, SLOTS>(cfg, compute_dtype, io, num_cus, name, supported); \
+    ++id;
+    LDPC_FOR_EACH_SPEC_CODE(LDPC_LAUNCH)
+#undef LDPC_LAUNCH
+    *supported = false;
+    return hipSuccess;
+#endif
+}
+
+}  // namespace ldpc

@@ -18,76 +18,9 @@
 // and sums in ascending check order (ldpc.py:173,188), then b = 0.75 * (S + L) (ldpc.py:196).
 #include <cstring>
 
-#include "bp_common.h"
-#include "bp_math.h"
-#include "gen/codes_gen.h"
+#include "spec_common.h"
 
 namespace ldpc {
-
-template <int I> struct IC { static constexpr int value = I; constexpr operator int() const { return I; } };
-template <int B, int E, class Fn>
-__device__ __forceinline__ void static_for(Fn &&fn)
-{
-    if constexpr (B < E) { fn(IC<B>{}); static_for<B + 1, E>(fn); }
-}
-
-template <typename T> struct SNum;
-template <> struct SNum<float> {
-    typedef float2 Pair;
-    __device__ static __forceinline__ unsigned sign_word(float x) { return __float_as_uint(x); }
-    __device__ static __forceinline__ float with_sign(float mag, unsigned s) {
-        return __uint_as_float(__float_as_uint(mag) | (s & 0x80000000u));
-    }
-    // written out as instructions: the min/max builtins put a quieting canonicalisation in front
-    // of every operand that comes from memory
-    __device__ static __forceinline__ float flip_sign(float x, unsigned signbit) {
-        return __uint_as_float(__float_as_uint(x) ^ signbit);
-    }
-    __device__ static __forceinline__ float min_abs(float m, float b) {
-        float d; asm("v_min_f32 %0, %1, |%2|" : "=v"(d) : "v"(m), "v"(b)); return d;
-    }
-    __device__ static __forceinline__ float second(float m1, float m2, float b) {  // m1 <= m2
-        float d; asm("v_med3_f32 %0, %1, %2, |%3|" : "=v"(d) : "v"(m1), "v"(m2), "v"(b)); return d;
-    }
-    __device__ static __forceinline__ Pair make(float a, float b) { return make_float2(a, b); }
-};
-template <> struct SNum<double> {
-    typedef double2 Pair;
-    __device__ static __forceinline__ unsigned sign_word(double x) { return (unsigned)__double2hiint(x); }
-    __device__ static __forceinline__ double with_sign(double mag, unsigned s) {
-        return __hiloint2double(__double2hiint(mag) | (int)(s & 0x80000000u), __double2loint(mag));
-    }
-    __device__ static __forceinline__ double flip_sign(double x, unsigned signbit) {
-        return __hiloint2double(__double2hiint(x) ^ (int)signbit, __double2loint(x));
-    }
-    __device__ static __forceinline__ double min_abs(double m, double b) {
-        double d; asm("v_min_f64 %0, %1, |%2|" : "=v"(d) : "v"(m), "v"(b)); return d;
-    }
-    __device__ static __forceinline__ double second(double m1, double m2, double b) {
-        double t, d;
-        asm("v_max_f64 %0, %1, |%2|" : "=v"(t) : "v"(m1), "v"(b));
-        asm("v_min_f64 %0, %1, %2" : "=v"(d) : "v"(m2), "v"(t));
-        return d;
-    }
-    __device__ static __forceinline__ Pair make(double a, double b) { return make_double2(a, b); }
-};
-
-constexpr bool is_pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
-
-// byte offset of element ((z + s) mod Z) of a Z-vector with ELEM-byte elements, given zb = z*ELEM
-template <int Z, int ELEM, int S>
-__device__ __forceinline__ unsigned rot_fwd(unsigned zb)
-{
-    if constexpr (S == 0) return zb;
-    else if constexpr (is_pow2(Z)) return (zb + S * ELEM) & (unsigned)(Z * ELEM - 1);
-    else { const unsigned t = zb + S * ELEM; return min(t, t - (unsigned)(Z * ELEM)); }
-}
-// ... of element ((z - s) mod Z)
-template <int Z, int ELEM, int S>
-__device__ __forceinline__ unsigned rot_bwd(unsigned zb)
-{
-    return rot_fwd<Z, ELEM, (Z - S) % Z>(zb);
-}
 
 template <class C, typename T, int F>
 struct SpecLayout {
@@ -454,196 +387,6 @@ spec_r1_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *
     }
 }
 
-// ------------------------------------------------------------------------------------------ LNMS
-// Row-layered normalised min-sum (build extension, see LDPC_RULE_LNMS in ldpc_amd.h).
-//
-// Only the posteriors P live in LDS ([NB][Z] per slot).  Thread (f, z) owns check (br, z) of every
-// block row and keeps that check's previous messages in three registers: A = scale * m1,
-// B = scale * m2 (smallest / second smallest input magnitude) and a word W holding the position
-// of the smallest input (bits 24-28), the sign parity of the inputs (bit 31) and the sign of each
-// input (low bits, first edge highest).  A layer is one block row: read P (rotated), subtract the
-// old message, update (m1, m2, signs), add the new message and write P back to the same place.
-// All checks of a block row touch distinct variables (no double-circulant blocks allowed), so the
-// block-parallel update equals the oracle's check-by-check sweep bit for bit.  Workgroups of more
-// than one wave put a barrier between layers.  For NR BG1 Z = 384 in float that is 102 KiB of LDS
-// and 138 state registers per thread; one-message-per-edge flooding would need 474 KiB.
-template <class C, typename T, int F>
-struct LnLayout {
-    static constexpr int THREADS = ((F * C::Z + 63) / 64) * 64;
-    static constexpr bool SINGLE = THREADS == 64;
-    static constexpr int P_BYTES = ((C::NB * C::Z * (int)sizeof(T) + 15) / 16) * 16;
-    // check state (A, B, W) of the first REG_LAYERS block rows lives in registers (about 128 of
-    // them), the rest in LDS, 16 bytes (float) or 32 bytes (double) per check
-    static constexpr int REGS_PER_LAYER = 2 * (int)sizeof(T) / 4 + 1;
-    static constexpr int REG_LAYERS = C::MB < 128 / REGS_PER_LAYER ? C::MB : 128 / REGS_PER_LAYER;
-    static constexpr int ST_STRIDE = sizeof(T) == 4 ? 16 : 32;
-    static constexpr int ST_BYTES = (C::MB - REG_LAYERS) * C::Z * ST_STRIDE;
-    static constexpr int SLOT_BYTES = ((P_BYTES + ST_BYTES + 127) / 128) * 128 + (F > 1 ? 32 : 0);
-    static constexpr int FLAG_OFF = F * SLOT_BYTES;
-    static constexpr int LDS_BYTES = FLAG_OFF + 16 * (int)sizeof(int);
-    static constexpr bool HAS_PAIRS = [] { for (int k = 0; k < C::EB; ++k) if (C::col_pair[k]) return true; return false; }();
-};
-
-template <class C, typename T, typename TL, int F>
-__global__ void __launch_bounds__((LnLayout<C, T, F>::THREADS))
-spec_lnms_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__restrict__ hard_out,
-                 int *__restrict__ iters_out, uint8_t *__restrict__ conv_out, T *__restrict__ post_out)
-{
-    typedef LnLayout<C, T, F> LY;
-    static_assert(C::MAX_DC <= 24, "sign bits and argmin index share one 32-bit word");
-    static_assert(!LY::HAS_PAIRS, "layered schedule needs single-circulant blocks");
-    constexpr int Z = C::Z, NB = C::NB, MB = C::MB, ST = sizeof(T);
-    constexpr int n = NB * Z;
-    extern __shared__ __align__(16) unsigned char smem[];
-
-    const int tid = threadIdx.x;
-    const bool lane_on = tid < F * Z;
-    const int f = lane_on ? tid / Z : 0;
-    const int z = lane_on ? tid - f * Z : 0;
-    unsigned char *P_b = smem + f * LY::SLOT_BYTES;
-    int *slot_bad = reinterpret_cast<int *>(smem + LY::FLAG_OFF);
-    const unsigned zb = (unsigned)z * ST;
-    const unsigned long long slot_mask = (Z >= 64 ? ~0ull : ((1ull << (Z & 63)) - 1ull)) << ((f * Z) & 63);
-
-    const long long groups = (frames + F - 1) / F;
-    for (long long grp = blockIdx.x; grp < groups; grp += gridDim.x) {
-        const long long frame = grp * F + f;
-        const bool active = lane_on && frame < frames;
-        constexpr int RL = LY::REG_LAYERS;
-        T A[RL], B[RL];
-        unsigned W[RL];
-        unsigned char *st_b = P_b + LY::P_BYTES + (unsigned)z * LY::ST_STRIDE;  // this thread's spilled check state
-        static_for<0, MB>([&](auto br) {
-            if constexpr (br < RL) { A[br] = (T)0; B[br] = (T)0; W[br] = 0u; }
-            else if (lane_on) {
-                T *sp = reinterpret_cast<T *>(st_b + (br - RL) * Z * LY::ST_STRIDE);
-                sp[0] = (T)0; sp[1] = (T)0;
-                *reinterpret_cast<unsigned *>(sp + 2) = 0u;
-            }
-        });
-        if (lane_on) {
-            static_for<0, NB>([&](auto bc) {
-                const T l = (active ? (T)llr[frame * n + bc * Z + z] : (T)0) + (T)0;  // -0.0 -> +0.0
-                *reinterpret_cast<T *>(P_b + bc * Z * ST + zb) = l;
-            });
-        }
-        if constexpr (!LY::SINGLE) {
-            if (tid < F) slot_bad[tid] = 0;
-            __syncthreads();
-        }
-
-        auto write_out = [&](int iters, int conv) {
-            static_for<0, NB>([&](auto bc) {
-                const T v = *reinterpret_cast<const T *>(P_b + bc * Z * ST + zb);
-                hard_out[frame * n + bc * Z + z] = (uint8_t)hard_bit<1>(v);
-                if (post_out) post_out[frame * n + bc * Z + z] = v;
-            });
-            if (z == 0) { iters_out[frame] = iters; conv_out[frame] = (uint8_t)conv; }
-        };
-
-        bool done = !active;
-        int t = 0;
-        for (;; ++t) {
-            const bool last = t == g.max_iters;
-            if (g.early_exit || last) {
-                // ---- syndrome of the hard decisions `0 if P > 0 else 1` of the current posteriors
-                int bad = 0;
-                if (!done && !(last && g.early_exit)) {
-                    static_for<0, MB>([&](auto br) {
-                        constexpr int e0 = C::row_ptr[br], D = C::row_ptr[br + 1] - e0;
-                        int par = 0;
-                        unsigned zl = zb;
-                        asm volatile("" : "+v"(zl));  // keep the rotated addresses out of loop-invariant hoisting
-                        static_for<0, D>([&](auto p) {
-                            constexpr int bc = C::row_col[e0 + p], s = C::row_shift[e0 + p];
-                            const T v = *reinterpret_cast<const T *>(P_b + bc * Z * ST + rot_fwd<Z, ST, s>(zl));
-                            par ^= (int)hard_bit<1>(v);
-                        });
-                        bad |= par;
-                    });
-                }
-                bool slot_ok;
-                if constexpr (LY::SINGLE) {
-                    slot_ok = (__ballot(bad) & slot_mask) == 0ull;
-                } else {
-                    if (bad) slot_bad[f] = 1;
-                    __syncthreads();
-                    slot_ok = slot_bad[f] == 0;
-                }
-                if (last) {
-                    if (!done) write_out(g.early_exit ? g.max_iters - 1 : g.max_iters, g.early_exit ? 0 : (slot_ok ? 1 : 0));
-                    break;
-                }
-                if (!done && slot_ok) { write_out(t, 1); done = true; }
-                if constexpr (LY::SINGLE) {
-                    if (__ballot(!done) == 0ull) break;
-                } else {
-                    if (!__syncthreads_or(!done)) break;
-                    if (tid < F) slot_bad[tid] = 0;
-                }
-            } else if (last) {
-                break;
-            }
-            // ---- layers: one block row after the other
-            static_for<0, MB>([&](auto br) {
-                constexpr int e0 = C::row_ptr[br], D = C::row_ptr[br + 1] - e0;
-                if constexpr (D >= 2) {
-                    if (!done) {
-                        T q[D];
-                        unsigned off[D];
-                        T Ao, Bo;
-                        unsigned w;
-                        if constexpr (br < RL) { Ao = A[br]; Bo = B[br]; w = W[br]; }
-                        else {
-                            const T *sp = reinterpret_cast<const T *>(st_b + (br - RL) * Z * LY::ST_STRIDE);
-                            Ao = sp[0]; Bo = sp[1];
-                            w = *reinterpret_cast<const unsigned *>(sp + 2);
-                        }
-                        const int idx_old = (int)((w >> 24) & 31u);
-                        T m1 = Lim<T>::inf(), m2 = Lim<T>::inf();
-                        unsigned sx = 0, sq = 0;
-                        unsigned zl = zb;
-                        asm volatile("" : "+v"(zl));  // as above: hundreds of hoisted addresses would spill
-                        static_for<0, D>([&](auto p) {
-                            constexpr int bc = C::row_col[e0 + p], s = C::row_shift[e0 + p];
-                            off[p] = rot_fwd<Z, ST, s>(zl) + bc * Z * ST;
-                            const T v = *reinterpret_cast<const T *>(P_b + off[p]);
-                            // previous message of this edge: magnitude B for the old argmin, else A;
-                            // sign = old parity (bit 31) xor old sign of q (bit D-1-p)
-                            const T mag = idx_old == p ? Bo : Ao;
-                            const T rold = SNum<T>::flip_sign(mag, ((w << (31 - (D - 1 - p))) ^ w) & 0x80000000u);
-                            q[p] = v - rold;
-                            m2 = SNum<T>::second(m1, m2, q[p]);
-                            m1 = SNum<T>::min_abs(m1, q[p]);
-                            const unsigned sw = SNum<T>::sign_word(q[p]);
-                            sx ^= sw;
-                            sq = (sq << 1) | (sw >> 31);
-                        });
-                        const T An = g.scale * m1, Bn = g.scale * m2;
-                        int idx = 0;
-                        static_for<0, D>([&](auto pp) {
-                            constexpr int p = D - 1 - pp;  // descending: the first minimum wins
-                            const bool ismin = t_abs(q[p]) == m1;
-                            idx = ismin ? p : idx;
-                            const T r = SNum<T>::flip_sign(ismin ? Bn : An, (sx ^ SNum<T>::sign_word(q[p])) & 0x80000000u);
-                            *reinterpret_cast<T *>(P_b + off[p]) = q[p] + r;
-                        });
-                        const unsigned wn = sq | ((unsigned)idx << 24) | (sx & 0x80000000u);
-                        if constexpr (br < RL) { A[br] = An; B[br] = Bn; W[br] = wn; }
-                        else {
-                            T *sp = reinterpret_cast<T *>(st_b + (br - RL) * Z * LY::ST_STRIDE);
-                            sp[0] = An; sp[1] = Bn;
-                            *reinterpret_cast<unsigned *>(sp + 2) = wn;
-                        }
-                    }
-                }
-                if constexpr (!LY::SINGLE) __syncthreads();
-            });
-        }
-        if constexpr (!LY::SINGLE) __syncthreads();
-    }
-}
-
 // ------------------------------------------------------------------------------------------ host
 template <class C>
 static bool code_matches(int Z, int mb, int nb, int Eb, const int *er, const int *ec, const int *es)
@@ -707,33 +450,6 @@ static hipError_t launch_spec_r1(const ldpc_decode_config &cfg, const Launch &io
     return hipGetLastError();
 }
 
-template <class C, typename T, typename TL, int F>
-static hipError_t launch_spec_lnms(const ldpc_decode_config &cfg, const Launch &io, int num_cus, const char **name)
-{
-    typedef LnLayout<C, T, F> LY;
-    Cfg<T> g;
-    g.rule = LDPC_RULE_LNMS; g.max_iters = cfg.max_iters; g.early_exit = cfg.early_exit;
-    g.float_syndrome0 = 0; g.num_active_checks = -1; g.num_refresh_vars = -1;
-    g.scale = (T)cfg.scale; g.clip_tanh_arg = (T)0; g.clip_prod = (T)0; g.clip_post = (T)0;
-    size_t per_cu = (160 * 1024) / LY::LDS_BYTES;
-    const size_t wave_cap = 32 / (LY::THREADS / 64);
-    if (per_cu > wave_cap) per_cu = wave_cap;
-    if (per_cu < 1) per_cu = 1;
-    const long long groups = (io.frames + F - 1) / F;
-    long long grid = (long long)num_cus * (long long)per_cu * 2;
-    if (grid > groups) grid = groups;
-    if (grid < 1) grid = 1;
-    auto k = spec_lnms_kernel<C, T, TL, F>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, LY::LDS_BYTES);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(LY::THREADS), LY::LDS_BYTES, io.stream, g,
-                       reinterpret_cast<const TL *>(io.llr), io.frames, io.hard, io.iters, io.converged,
-                       reinterpret_cast<T *>(io.posterior));
-    *name = sizeof(T) == 8 ? "spec_lnms_f64" : "spec_lnms_f32";
-    return hipGetLastError();
-}
-
 template <class C, int F>
 static hipError_t launch_spec_code(const ldpc_decode_config &cfg, int compute_dtype, const Launch &io,
                                    int num_cus, const char **name, bool *supported)
@@ -757,20 +473,6 @@ static hipError_t launch_spec_code(const ldpc_decode_config &cfg, int compute_dt
             if (io.llr_dtype == LDPC_F32) return launch_spec_r1<C, float, float, F>(cfg, io, num_cus, name);
         }
     }
-    if constexpr (!LnLayout<C, float, F>::HAS_PAIRS && C::MAX_DC <= 24) {
-        if (cfg.rule == LDPC_RULE_LNMS) {
-            if constexpr (LnLayout<C, double, F>::LDS_BYTES <= 160 * 1024) {
-                if (compute_dtype == LDPC_F64) {
-                    if (io.llr_dtype == LDPC_F64) return launch_spec_lnms<C, double, double, F>(cfg, io, num_cus, name);
-                    return launch_spec_lnms<C, double, float, F>(cfg, io, num_cus, name);
-                }
-            }
-            if constexpr (LnLayout<C, float, F>::LDS_BYTES <= 160 * 1024) {
-                if (compute_dtype == LDPC_F32 && io.llr_dtype == LDPC_F32)
-                    return launch_spec_lnms<C, float, float, F>(cfg, io, num_cus, name);
-            }
-        }
-    }
     *supported = false;
     return hipSuccess;
 }
@@ -789,6 +491,8 @@ int spec_match(int Z, int mb, int nb, int Eb, const int *er, const int *ec, cons
 hipError_t launch_spec(int spec_id, const ldpc_decode_config &cfg, int compute_dtype, const Launch &io,
                        int num_cus, const char **name, bool *supported)
 {
+    if (cfg.rule == LDPC_RULE_LNMS)  // decode_lnms.hip
+        return launch_spec_lnms(spec_id, cfg, compute_dtype, io, num_cus, name, supported);
     int id = 0;
 #define LDPC_LAUNCH(CODE, SLOTS)                                                                   \
     if (spec_id == id) return launch_spec_code<CODE, SLOTS>(cfg, compute_dtype, io, num_cus, name, supported); \

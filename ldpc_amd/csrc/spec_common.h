@@ -1,0 +1,75 @@
+// Helpers shared by the code-specialised kernels: compile-time loops over the generated circulant
+// tables, sign/magnitude primitives written as single instructions, rotated LDS offsets.
+#pragma once
+#include "bp_common.h"
+#include "bp_math.h"
+#include "gen/codes_gen.h"
+
+namespace ldpc {
+
+template <int I> struct IC { static constexpr int value = I; constexpr operator int() const { return I; } };
+template <int B, int E, class Fn>
+__device__ __forceinline__ void static_for(Fn &&fn)
+{
+    if constexpr (B < E) { fn(IC<B>{}); static_for<B + 1, E>(fn); }
+}
+
+template <typename T> struct SNum;
+template <> struct SNum<float> {
+    typedef float2 Pair;
+    __device__ static __forceinline__ unsigned sign_word(float x) { return __float_as_uint(x); }
+    __device__ static __forceinline__ float with_sign(float mag, unsigned s) {
+        return __uint_as_float(__float_as_uint(mag) | (s & 0x80000000u));
+    }
+    // written out as instructions: the min/max builtins put a quieting canonicalisation in front
+    // of every operand that comes from memory
+    __device__ static __forceinline__ float flip_sign(float x, unsigned signbit) {
+        return __uint_as_float(__float_as_uint(x) ^ signbit);
+    }
+    __device__ static __forceinline__ float min_abs(float m, float b) {
+        float d; asm("v_min_f32 %0, %1, |%2|" : "=v"(d) : "v"(m), "v"(b)); return d;
+    }
+    __device__ static __forceinline__ float second(float m1, float m2, float b) {  // m1 <= m2
+        float d; asm("v_med3_f32 %0, %1, %2, |%3|" : "=v"(d) : "v"(m1), "v"(m2), "v"(b)); return d;
+    }
+    __device__ static __forceinline__ Pair make(float a, float b) { return make_float2(a, b); }
+};
+template <> struct SNum<double> {
+    typedef double2 Pair;
+    __device__ static __forceinline__ unsigned sign_word(double x) { return (unsigned)__double2hiint(x); }
+    __device__ static __forceinline__ double with_sign(double mag, unsigned s) {
+        return __hiloint2double(__double2hiint(mag) | (int)(s & 0x80000000u), __double2loint(mag));
+    }
+    __device__ static __forceinline__ double flip_sign(double x, unsigned signbit) {
+        return __hiloint2double(__double2hiint(x) ^ (int)signbit, __double2loint(x));
+    }
+    __device__ static __forceinline__ double min_abs(double m, double b) {
+        double d; asm("v_min_f64 %0, %1, |%2|" : "=v"(d) : "v"(m), "v"(b)); return d;
+    }
+    __device__ static __forceinline__ double second(double m1, double m2, double b) {
+        double t, d;
+        asm("v_max_f64 %0, %1, |%2|" : "=v"(t) : "v"(m1), "v"(b));
+        asm("v_min_f64 %0, %1, %2" : "=v"(d) : "v"(m2), "v"(t));
+        return d;
+    }
+    __device__ static __forceinline__ Pair make(double a, double b) { return make_double2(a, b); }
+};
+
+constexpr bool is_pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
+
+// byte offset of element ((z + s) mod Z) of a Z-vector with ELEM-byte elements, given zb = z*ELEM
+template <int Z, int ELEM, int S>
+__device__ __forceinline__ unsigned rot_fwd(unsigned zb)
+{
+    if constexpr (S == 0) return zb;
+    else if constexpr (is_pow2(Z)) return (zb + S * ELEM) & (unsigned)(Z * ELEM - 1);
+    else { const unsigned t = zb + S * ELEM; return min(t, t - (unsigned)(Z * ELEM)); }
+}
+// ... of element ((z - s) mod Z)
+template <int Z, int ELEM, int S>
+__device__ __forceinline__ unsigned rot_bwd(unsigned zb)
+{
+    return rot_fwd<Z, ELEM, (Z - S) % Z>(zb);
+}
+
+}  // namespace ldpc

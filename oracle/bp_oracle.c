@@ -262,7 +262,9 @@ int bp_oracle_decode(const oracle_code *code, const oracle_cfg *cfg, const doubl
  * Build extension (nothing in the reference corresponds to it): checks in ascending order, each
  * working on the current posteriors.  Generated for double and for float so that the float GPU
  * kernel has a bit-exact CPU counterpart.  The channel LLR is stored as L + 0 (no -0.0 anywhere,
- * so "negative" and "sign bit set" coincide).
+ * so "negative" and "sign bit set" coincide).  A variable that takes part in one check only
+ * sends that check its channel LLR itself: its extrinsic information is exactly that, and
+ * (L + r) - r would only add rounding noise.
  */
 #define DEFINE_LNMS(NAME, REAL, FABS)                                                              \
     static void NAME(const oracle_code *c, const oracle_cfg *g, const double *Lin, REAL *P, REAL *R, \
@@ -270,6 +272,7 @@ int bp_oracle_decode(const oracle_code *code, const oracle_cfg *cfg, const doubl
     {                                                                                              \
         const int n = c->n, m = c->m;                                                              \
         const REAL scale = (REAL)g->scale;                                                         \
+        const int *cp = c->col_ptr;                                                                \
         REAL q[64];                                                                                \
         for (int i = 0; i < n; i++) { P[i] = (REAL)Lin[i] + (REAL)0; hard[i] = P[i] > 0 ? 0 : 1; } \
         for (int e = 0; e < c->E; e++) R[e] = (REAL)0;                                             \
@@ -282,7 +285,8 @@ int bp_oracle_decode(const oracle_code *code, const oracle_cfg *cfg, const doubl
                 REAL m1 = INFINITY, m2 = INFINITY;                                                 \
                 int neg = 0;                                                                       \
                 for (int p = 0; p < d; p++) {                                                      \
-                    q[p] = P[c->col_idx[e0 + p]] - R[e0 + p];                                      \
+                    const int i = c->col_idx[e0 + p];                                              \
+                    q[p] = cp[i + 1] - cp[i] == 1 ? (REAL)Lin[i] + (REAL)0 : P[i] - R[e0 + p];     \
                     REAL a = FABS(q[p]);                                                           \
                     if (a < m1) { m2 = m1; m1 = a; } else if (a < m2) { m2 = a; }                  \
                     neg ^= q[p] < 0;                                                               \

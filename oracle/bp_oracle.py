@@ -309,11 +309,14 @@ def _load_c():
 
 def numpy_decode_lnms(code, cfg, llr, dtype=np.float64):
     """Row-layered normalised min-sum (build extension, no counterpart in the reference): checks in
-    ascending order on the current posteriors; q = P - r_old, r_new = scale * min-of-others * sign,
-    P = q + r_new.  Syndrome test at the top of each iteration, R1's polarity and conventions."""
+    ascending order on the current posteriors; q = P - r_old (the channel LLR itself for a variable
+    that takes part in this check only), r_new = scale * min-of-others * sign, P = q + r_new.
+    Syndrome test at the top of each iteration, R1's polarity and conventions."""
     L = np.array(llr, dtype=np.float64, ndmin=2)
     B, n = L.shape
     P = L.astype(dtype) + dtype(0)
+    L0 = P.copy()
+    lone = np.diff(code.col_ptr) == 1
     R = np.zeros((B, code.num_edges), dtype)
     scale = dtype(cfg.scale)
     hard = np.where(P > 0, 0, 1).astype(np.uint8)
@@ -338,7 +341,7 @@ def numpy_decode_lnms(code, cfg, llr, dtype=np.float64):
             if d < 2:
                 continue
             cols = code.col_idx[e0:e1]
-            q = P[:, cols] - R[:, e0:e1]
+            q = np.where(lone[cols][None, :], L0[:, cols], P[:, cols] - R[:, e0:e1])
             a = np.abs(q)
             srt = np.sort(a, axis=1)
             m1, m2 = srt[:, 0], srt[:, 1]

@@ -48,7 +48,6 @@ def test_numpy_and_c_layered_oracles_agree(name, c_oracle):
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["wifi648", "nr_bg2_z40", "nr_bg2_z40_r1400", "nr_bg1_z384"])
 def test_layered_kernel_matches_oracle(name, c_oracle):
-    from ldpc_amd import _lib
     from ldpc_amd.decoder import Decoder
     code = codes.load_packaged(name)
     dec = Decoder(code)
@@ -63,12 +62,6 @@ def test_layered_kernel_matches_oracle(name, c_oracle):
         assert np.array_equal(res.posterior.astype(np.float64), ep)
         if cfg.early_exit:
             assert 0 < ec.sum()
-        if name == "nr_bg1_z384":
-            # posteriors of this code do not fit LDS in double
-            with pytest.raises(_lib.LdpcError) as ei_:
-                dec.decode(L, cfg, compute_dtype=np.float64)
-            assert ei_.value.code == _lib.LDPC_ERR_UNSUPPORTED
-            continue
         eh, ei, ec, ep = c_oracle.c_decode_lnms(code, cfg, L)
         res = dec.decode(L, cfg, compute_dtype=np.float64, want_posterior=True)
         assert res.kernel == "spec_lnms_f64"
