@@ -106,37 +106,39 @@ struct LnPlan {
     }
 };
 
+// LDS of one frame slot: [state of the first spilled block row, or padding][P][state of the other
+// spilled block rows].  P starts at least one Z-vector into the slot so that "one vector back"
+// never leaves the slot (see ln_addr).
 template <class C, typename T, int F, int RL>
 struct LnLayout {
     typedef LnPlan<C> PL;
     static constexpr int ST = sizeof(T);
+    static constexpr int VEC = C::Z * ST;                    // bytes of one Z-vector of T
     static constexpr int THREADS = ((F * C::Z + 63) / 64) * 64;
     static constexpr bool SINGLE = THREADS == 64;
-    static constexpr int P_BYTES = ((PL::NS * C::Z * ST + 15) / 16) * 16;
+    static constexpr int P_BYTES = ((PL::NS * VEC + 15) / 16) * 16;
     static constexpr int LAYER_BYTES = C::Z * (2 * ST + 4);  // A[Z], B[Z], W[Z] of one spilled block row
-    static constexpr int ST_BYTES = (C::MB - RL) * LAYER_BYTES;
-    static constexpr int SLOT_BYTES = ((P_BYTES + ST_BYTES + 127) / 128) * 128 + (F > 1 ? 32 : 0);
+    static constexpr int SPILLED = C::MB - RL;
+    static constexpr int P_OFF = SPILLED > 0 ? LAYER_BYTES : ((VEC + 15) / 16) * 16;
+    static constexpr int REST_OFF = P_OFF + P_BYTES;
+    static constexpr int SLOT_BYTES = ((REST_OFF + (SPILLED > 1 ? SPILLED - 1 : 0) * LAYER_BYTES + 127) / 128) * 128 + (F > 1 ? 32 : 0);
     static constexpr int FLAG_OFF = F * SLOT_BYTES;
     static constexpr int LDS_BYTES = FLAG_OFF + 64;
-    // rotated offsets from one packed add and one 16-bit minimum: needs 2 * Z * ST and the
-    // posterior area below 64 KiB
-    static constexpr bool PACKED_ROT = !is_pow2(C::Z) && 2 * C::Z * ST <= 65535 && P_BYTES <= 65535;
+    // slot offset of the state of spilled block row k = br - RL
+    static constexpr int state_off(int k) { return k == 0 ? 0 : REST_OFF + (k - 1) * LAYER_BYTES; }
 };
 
-// offset of element ((z + S) mod Z); zz = zb | ((zb - Z * ST) mod 2^16) << 16.  Adding S * ST to
-// both halves at once gives the unwrapped and the wrapped candidate; the smaller one (as
-// unsigned 16-bit numbers) is the answer.
-template <int Z, int ST, int S, bool PACKED>
-__device__ __forceinline__ unsigned ln_rot(unsigned zb, unsigned zz)
+// LDS address of element ((z + S) mod Z) of shared column CI.  zl = z * ST; zbP = slot base + zl,
+// zbPW = zbP + one vector.  The wrapped and the unwrapped case differ by one vector, so one
+// compare against a constant and one select pick the base register, and everything else is a
+// constant that lands in the instruction's offset field.
+template <class LY, int CI, int S>
+__device__ __forceinline__ unsigned ln_addr(unsigned zl, unsigned zbP, unsigned zbPW)
 {
-    if constexpr (S == 0) return zb;
-    else if constexpr (!PACKED) return rot_fwd<Z, ST, S>(zb);
+    if constexpr (S == 0) return zbP + (unsigned)(LY::P_OFF + CI * LY::VEC);
     else {
-        const unsigned t = zz + (unsigned)(S * ST) * 0x10001u;
-        unsigned a;
-        asm("v_min_u32_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1"
-            : "=v"(a) : "v"(t));
-        return a;
+        const unsigned base = zl >= (unsigned)(LY::VEC - S * LY::ST) ? zbP : zbPW;
+        return base + (unsigned)(LY::P_OFF + CI * LY::VEC + S * LY::ST - LY::VEC);
     }
 }
 
@@ -164,42 +166,48 @@ lnms_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__r
     static_assert(PL::supported(), "code shape not supported by the layered kernel");
     constexpr int Z = C::Z, NB = C::NB, MB = C::MB, ST = sizeof(T);
     constexpr int n = NB * Z;
-    constexpr bool PK = LY::PACKED_ROT;
     extern __shared__ __align__(16) unsigned char smem[];
 
     const int tid = threadIdx.x;
     const bool lane_on = tid < F * Z;
     const int f = (F == 1 || !lane_on) ? 0 : tid / Z;
     const int z = lane_on ? tid - f * Z : 0;
-    const unsigned P_b = (unsigned)f * LY::SLOT_BYTES;               // [NS][Z] T, absolute LDS address
-    const unsigned stA = P_b + LY::P_BYTES + (unsigned)z * ST;       // spilled check state of this thread
-    const unsigned stW = P_b + LY::P_BYTES + 2 * Z * ST + (unsigned)z * 4;
-    int *slot_bad = reinterpret_cast<int *>(smem + LY::FLAG_OFF);
     const unsigned zb = (unsigned)z * ST;
-    const unsigned zz = zb | (((zb - (unsigned)(Z * ST)) & 0xffffu) << 16);
+    const unsigned zbP = (unsigned)f * LY::SLOT_BYTES + zb;          // absolute LDS addresses from here on
+    const unsigned zbPW = zbP + LY::VEC;
+    const unsigned stA = zbP;                                        // spilled check state of this thread
+    const unsigned stW = (unsigned)f * LY::SLOT_BYTES + 2 * Z * ST + (unsigned)z * 4;
+    int *slot_bad = reinterpret_cast<int *>(smem + LY::FLAG_OFF);
     const unsigned long long slot_mask = (Z >= 64 ? ~0ull : ((1ull << (Z & 63)) - 1ull)) << ((f * Z) & 63);
 
     const long long groups = (frames + F - 1) / F;
     for (long long grp = blockIdx.x; grp < groups; grp += gridDim.x) {
         const long long frame = F == 1 ? grp : grp * F + f;
         const bool active = lane_on && frame < frames;
-        // loads never depend on `active`: idle lanes read a frame that exists
+        // loads never depend on `active`: idle lanes read a frame that exists.  The group's first
+        // frame is the same for every lane (a scalar base address), the rest is a 32-bit offset.
+#ifdef LDPC_LNMS_LANE_POINTERS
         const TL *__restrict__ lf = llr + (frame < frames ? frame : frames - 1) * n;
+        const unsigned fo = (unsigned)z;
+#else
+        const TL *__restrict__ lf = llr + grp * F * n;
+        const unsigned fo = (frame < frames ? (unsigned)f : 0u) * (unsigned)n + (unsigned)z;
+#endif
 
         T A[RL > 0 ? RL : 1], B[RL > 0 ? RL : 1];
         unsigned W[RL > 0 ? RL : 1];
         static_for<0, MB>([&](auto br) {
             if constexpr (br < RL) { A[br] = (T)0; B[br] = (T)0; W[br] = 0u; }
             else if (lane_on) {
-                lds_put<T>(stA + (br - RL) * LY::LAYER_BYTES, (T)0);
-                lds_put<T>(stA + (br - RL) * LY::LAYER_BYTES + Z * ST, (T)0);
-                lds_put<unsigned>(stW + (br - RL) * LY::LAYER_BYTES, 0u);
+                lds_put<T>(stA + LY::state_off(br - RL), (T)0);
+                lds_put<T>(stA + LY::state_off(br - RL) + Z * ST, (T)0);
+                lds_put<unsigned>(stW + LY::state_off(br - RL), 0u);
             }
         });
         static_for<0, NB>([&](auto bc) {
             if constexpr (PL::shared(bc)) {
-                const T l = (T)lf[bc * Z + z] + (T)0;  // -0.0 -> +0.0: "negative" is "sign bit set" from here on
-                if (lane_on) lds_put<T>(P_b + PL::lds_index(bc) * Z * ST + zb, l);  // idle lanes alias lane 0
+                const T l = (T)lf[fo + (unsigned)(bc * Z)] + (T)0;  // -0.0 -> +0.0: "negative" is "sign bit set" from here on
+                if (lane_on) lds_put<T>(ln_addr<LY, PL::lds_index(bc), 0>(zb, zbP, zbPW), l);  // idle lanes alias lane 0
             }
         });
         if constexpr (!LY::SINGLE) {
@@ -210,9 +218,9 @@ lnms_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__r
         auto load_state = [&](auto br, T &a, T &b, unsigned &w) {
             if constexpr (br < RL) { a = A[br]; b = B[br]; w = W[br]; }
             else {
-                a = lds_get<T>(stA + (br - RL) * LY::LAYER_BYTES);
-                b = lds_get<T>(stA + (br - RL) * LY::LAYER_BYTES + Z * ST);
-                w = lds_get<unsigned>(stW + (br - RL) * LY::LAYER_BYTES);
+                a = lds_get<T>(stA + LY::state_off(br - RL));
+                b = lds_get<T>(stA + LY::state_off(br - RL) + Z * ST);
+                w = lds_get<unsigned>(stW + LY::state_off(br - RL));
             }
         };
         // index inside the frame, and channel LLR, of the private variable of block row br
@@ -223,7 +231,13 @@ lnms_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__r
             if constexpr (s == 0) return bc * Z + zo;
             else { const int v = zo + s; return bc * Z + (v >= Z ? v - Z : v); }
         };
-        auto load_priv = [&](auto br) -> T { return (T)lf[priv_index(br)] + (T)0; };
+        auto load_priv = [&](auto br) -> T {
+            constexpr int e = C::row_ptr[br] + PL::priv_pos(br), bc = C::row_col[e], s = C::row_shift[e];
+            unsigned o = fo;
+            asm volatile("" : "+v"(o));  // one address per block row, computed where it is used
+            if constexpr (s != 0) o += (unsigned)z + s >= (unsigned)Z ? (unsigned)(s - Z) : (unsigned)s;
+            return (T)lf[o + (unsigned)(bc * Z)] + (T)0;
+        };
         // posterior L + r of that variable, r rebuilt from the check's state
         auto priv_value = [&](auto br) -> T {
             constexpr int D = PL::rdeg(br), p = PL::priv_pos(br);
@@ -241,8 +255,8 @@ lnms_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__r
             static_for<0, NB>([&](auto bc) {
                 if constexpr (PL::cdeg(bc) != 1) {
                     T v;
-                    if constexpr (PL::shared(bc)) v = lds_get<T>(P_b + PL::lds_index(bc) * Z * ST + zb);
-                    else v = (T)lf[bc * Z + z] + (T)0;  // in no check at all: the channel decides
+                    if constexpr (PL::shared(bc)) v = lds_get<T>(ln_addr<LY, PL::lds_index(bc), 0>(zb, zbP, zbPW));
+                    else v = (T)lf[fo + (unsigned)(bc * Z)] + (T)0;  // in no check at all: the channel decides
                     hard_out[frame * n + bc * Z + z] = (uint8_t)hard_bit<1>(v);
                     if (post_out) post_out[frame * n + bc * Z + z] = v;
                 }
@@ -272,13 +286,13 @@ lnms_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__r
                     static_for<0, MB>([&](auto br) {
                         constexpr int e0 = C::row_ptr[br], D = C::row_ptr[br + 1] - e0, PP = PL::priv_pos(br);
                         unsigned par = 0;
-                        unsigned zl = zb, zzl = zz;
-                        asm volatile("" : "+v"(zl), "+v"(zzl));  // keep the rotated addresses out of loop-invariant hoisting
+                        unsigned zl = zb;
+                        asm volatile("" : "+v"(zl));  // keep the rotated addresses out of loop-invariant hoisting
                         static_for<0, D>([&](auto p) {
                             if constexpr (p == PP) par ^= hard_bit<1>(priv_value(br));
                             else {
                                 constexpr int bc = C::row_col[e0 + p], s = C::row_shift[e0 + p];
-                                const T v = lds_get<T>(P_b + PL::lds_index(bc) * Z * ST + ln_rot<Z, ST, s, PK>(zl, zzl));
+                                const T v = lds_get<T>(ln_addr<LY, PL::lds_index(bc), s>(zl, zbP, zbPW));
                                 par ^= hard_bit<1>(v);
                             }
                         });
@@ -328,15 +342,15 @@ lnms_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__r
                         const unsigned wp = w ^ (unsigned)((int)w >> 31);  // bit D-1-p: sign of the old message on edge p
                         T m1 = Lim<T>::inf(), m2 = Lim<T>::inf();
                         unsigned sq = 0;
-                        unsigned zl = zb, zzl = zz;
-                        asm volatile("" : "+v"(zl), "+v"(zzl));  // as above: hundreds of hoisted addresses would spill
+                        unsigned zl = zb;
+                        asm volatile("" : "+v"(zl));  // as above: hundreds of hoisted addresses would spill
                         static_for<0, D>([&](auto p) {
                             if constexpr (p == PP) {
                                 q[p] = lp;  // a variable of degree one always sends its channel LLR
                                 off[p] = 0;
                             } else {
                                 constexpr int bc = C::row_col[e0 + p], s = C::row_shift[e0 + p];
-                                off[p] = P_b + ln_rot<Z, ST, s, PK>(zl, zzl) + PL::lds_index(bc) * Z * ST;
+                                off[p] = ln_addr<LY, PL::lds_index(bc), s>(zl, zbP, zbPW);
                                 const T v = lds_get<T>(off[p]);
                                 // previous message of this edge: magnitude B for the old argmin, else A
                                 const T mag = idx_old == p ? Bo : Ao;
@@ -348,22 +362,23 @@ lnms_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__r
                         });
                         const unsigned px = (unsigned)__popc(sq) << 31;  // sign parity of the inputs
                         const T An = g.scale * m1, Bn = g.scale * m2;
+                        const T Anp = SNum<T>::flip_sign(An, px), Bnp = SNum<T>::flip_sign(Bn, px);  // parity folded in
                         int idx = 0;
                         static_for<0, D>([&](auto pp) {
                             constexpr int p = D - 1 - pp;  // descending: the first minimum wins
                             const bool ismin = t_abs(q[p]) == m1;
                             idx = ismin ? p : idx;
                             if constexpr (p != PP) {
-                                const T r = SNum<T>::flip_sign(ismin ? Bn : An, (px ^ SNum<T>::sign_word(q[p])) & 0x80000000u);
+                                const T r = SNum<T>::flip_sign(ismin ? Bnp : Anp, SNum<T>::sign_word(q[p]) & 0x80000000u);
                                 lds_put<T>(off[p], q[p] + r);
                             }
                         });
                         const unsigned wn = sq | ((unsigned)idx << 24) | px;
                         if constexpr (br < RL) { A[br] = An; B[br] = Bn; W[br] = wn; }
                         else {
-                            lds_put<T>(stA + (br - RL) * LY::LAYER_BYTES, An);
-                            lds_put<T>(stA + (br - RL) * LY::LAYER_BYTES + Z * ST, Bn);
-                            lds_put<unsigned>(stW + (br - RL) * LY::LAYER_BYTES, wn);
+                            lds_put<T>(stA + LY::state_off(br - RL), An);
+                            lds_put<T>(stA + LY::state_off(br - RL) + Z * ST, Bn);
+                            lds_put<unsigned>(stW + LY::state_off(br - RL), wn);
                         }
                     }
                 }
