@@ -275,14 +275,18 @@ lnms_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__r
         T lp_cur = (T)0;  // channel LLR of the next private variable the sweep will need
         if constexpr (PL::first_priv_layer() >= 0) lp_cur = load_priv(IC<(PL::first_priv_layer() >= 0 ? PL::first_priv_layer() : 0)>{});
 
+        // A slot that has converged is left alone (its posteriors and check state stay as they were
+        // at the successful test) and everything is written once, after the loop.
         bool done = !active;
+        int res_iters = g.early_exit ? g.max_iters - 1 : g.max_iters, res_conv = 0;
         for (int t = 0;; ++t) {
             const bool last = t == g.max_iters;
             if (g.early_exit || last) {
                 // ---- syndrome of the hard decisions `0 if P > 0 else 1` of the current posteriors
                 if constexpr (!LY::SINGLE) __syncthreads();
+                if (last && g.early_exit) break;  // no test after the last sweep
                 unsigned bad = 0;
-                if (!done && !(last && g.early_exit)) {
+                if (!done) {
                     static_for<0, MB>([&](auto br) {
                         constexpr int e0 = C::row_ptr[br], D = C::row_ptr[br + 1] - e0, PP = PL::priv_pos(br);
                         unsigned par = 0;
@@ -309,10 +313,10 @@ lnms_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__r
                     static_for<0, F>([&](auto ff) { any_bad |= slot_bad[ff] != 0; });
                 }
                 if (last) {
-                    if (!done) write_out(g.early_exit ? g.max_iters - 1 : g.max_iters, g.early_exit ? 0 : (slot_ok ? 1 : 0));
+                    if (!done) res_conv = slot_ok ? 1 : 0;
                     break;
                 }
-                if (!done && slot_ok) { write_out(t, 1); done = true; }
+                if (!done && slot_ok) { res_iters = t; res_conv = 1; done = true; }
                 if constexpr (LY::SINGLE) {
                     if (__ballot(!done) == 0ull) break;
                 } else {
@@ -384,6 +388,7 @@ lnms_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__r
                 }
             });
         }
+        if (active) write_out(res_iters, res_conv);
         if constexpr (!LY::SINGLE) __syncthreads();
     }
 }
