@@ -17,7 +17,8 @@ Rank 0 prints one JSON line.  Beside the headline value it carries
   lds_roofline  algorithmic LDS bytes of the executed iterations against the nominal LDS rate
   cpu_baseline  the CPU restatement (oracle/bp_oracle.c, OpenMP) timed on a bounded sample of the
                 same LLRs on this host, which doubles as a parity check of that sample
-  other         secondary workloads (early exit at an operating SNR, float32, rule R1), N=1 only
+  other         secondary workloads (early exit at an operating SNR, float32, rule R1, NR BG1
+                Z=384 layered min-sum), aggregated over all ranks like the headline
 """
 import argparse
 import glob
@@ -36,7 +37,9 @@ LDS_PEAK_GBS = 128 * 256 * 2.4   # 128 B/clk/CU x 256 CUs x 2.4 GHz = 78.6 TB/s 
 
 
 def lds_bytes_per_frame_iter(code, rule, itemsize):
-    """Algorithmic LDS traffic of one flooding iteration of one frame."""
+    """Algorithmic LDS traffic of one iteration of one frame: flooding extrinsic rules read and
+    write one message per edge in both phases (16 E), R0 12 E + 4 n, layered min-sum reads and
+    writes one posterior per edge (8 E) plus its compressed check state (24 m)."""
     E, n = code.num_edges, code.n
     per4 = (12 * E + 4 * n) if rule == 0 else (8 * E + 24 * code.m if rule == 5 else 16 * E)
     return per4 * itemsize // 4
@@ -185,8 +188,8 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(code, cfg, batch, k_info, args)
-    if rank == 0 and world == 1 and not args.no_other and args.code == "ccsds512":
-        out["other"] = other_workloads(code, G, dec, args, torch, dist, device)
+    if not args.no_other and args.code == "ccsds512":
+        out["other"] = other_workloads(code, G, dec, args, torch, dist, device, world, rank)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -225,22 +228,24 @@ def cpu_baseline(code, cfg, batch, k_info, args):
             "gpu_results_identical_on_sample": bool(same) if (args.dtype == "f64" or cfg.rule == 5) else None}
 
 
-def other_workloads(code, G, dec, args, torch, dist, device):
-    """Secondary workloads, 3 timed launches each.  `frames` are per launch."""
+def other_workloads(code, G, dec, args, torch, dist, device, world, rank):
+    """Secondary workloads, 3 timed launches each on every rank; Gbit/s over all ranks, `frames`
+    per launch and per GPU."""
     from ldpc_amd import codes, config, sweep
     from ldpc_amd.decoder import Decoder
     res = {}
 
     def run(label, code_, G_, dec_, rule, dtype, snr, early, frames, k_info):
         cfg = config.PRESETS[rule].with_(max_iters=args.max_iters, early_exit=early)
-        batch = sweep.make_batch(code_, G_, frames, snr, cfg, seed=[8, len(label)], device=device)
+        batch = sweep.make_batch(code_, G_, frames, snr, cfg, seed=[8, len(label), rank], device=device)
         compute = np.float64 if dtype == "f64" else np.float32
         wall, dev_ms = timed_steps(lambda: sweep.decode_batch(dec_, batch, cfg, compute_dtype=compute),
-                                   3, 1, torch, dist, 1)
+                                   3, 1, torch, dist, world)
         sweep.count_errors(dec_, batch)
+        sweep.allreduce_counters(batch.counters)
         torch.cuda.synchronize()
         st = sweep.summarize(batch.counters.cpu().numpy(), code_.n)
-        res[label] = {"gbit_s": frames * 3 * k_info / wall / 1e9, "mean_iters": st["mean_iters"],
+        res[label] = {"gbit_s": frames * world * 3 * k_info / wall / 1e9, "mean_iters": st["mean_iters"],
                       "fer": st["fer"], "ber": st["ber"], "frames": frames, "code": code_.name, "rule": rule,
                       "dtype": dtype, "es_n0_db": snr, "early_exit": early}
 
@@ -260,6 +265,7 @@ def other_workloads(code, G, dec, args, torch, dist, device):
     dec1 = Decoder(bg1)
     run("BG1_Z384_LNMS_f32_fixed_10", bg1, None, dec1, "LNMS", "f32", -3.0, False, 16384, bg1.n - bg1.m)
     run("BG1_Z384_LNMS_f32_es_n0_-3dB", bg1, None, dec1, "LNMS", "f32", -3.0, True, 16384, bg1.n - bg1.m)
+    run("BG1_Z384_LNMS_f32_es_n0_0dB", bg1, None, dec1, "LNMS", "f32", 0.0, True, 16384, bg1.n - bg1.m)
     return res
 
 

@@ -98,6 +98,44 @@ struct LnPlan {
         return -1;
     }
     static constexpr int first_priv_layer() { return next_priv_layer(C::MB - 1); }
+    // j-th layer with a private variable, their number, and the inverse map
+    static constexpr int n_priv_layers()
+    {
+        int c = 0;
+        for (int br = 0; br < C::MB; ++br) c += is_priv_layer(br);
+        return c;
+    }
+    static constexpr int priv_layer(int j)
+    {
+        for (int br = 0; br < C::MB; ++br)
+            if (is_priv_layer(br) && j-- == 0) return br;
+        return 0;
+    }
+    static constexpr int priv_layer_ord(int br)
+    {
+        int c = 0;
+        for (int r = 0; r < br; ++r) c += is_priv_layer(r);
+        return c;
+    }
+    // the same over all block rows that have a private variable (layers or not)
+    static constexpr int n_priv_rows()
+    {
+        int c = 0;
+        for (int br = 0; br < C::MB; ++br) c += priv_pos(br) >= 0;
+        return c;
+    }
+    static constexpr int priv_row(int j)
+    {
+        for (int br = 0; br < C::MB; ++br)
+            if (priv_pos(br) >= 0 && j-- == 0) return br;
+        return 0;
+    }
+    static constexpr int priv_row_ord(int br)
+    {
+        int c = 0;
+        for (int r = 0; r < br; ++r) c += priv_pos(r) >= 0;
+        return c;
+    }
     static constexpr int barriers_per_sweep()
     {
         int c = 0;
@@ -239,9 +277,8 @@ lnms_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__r
             return (T)lf[o + (unsigned)(bc * Z)] + (T)0;
         };
         // posterior L + r of that variable, r rebuilt from the check's state
-        auto priv_value = [&](auto br) -> T {
+        auto priv_value = [&](auto br, T l) -> T {
             constexpr int D = PL::rdeg(br), p = PL::priv_pos(br);
-            const T l = load_priv(br);
             if constexpr (D < 2) return l;
             else {
                 T a, b;
@@ -251,6 +288,8 @@ lnms_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__r
                 return l + SNum<T>::flip_sign(mag, ((w << (31 - (D - 1 - p))) ^ w) & 0x80000000u);
             }
         };
+        // channel LLRs of private variables are requested PFR block rows ahead of their use
+        constexpr int NPR = PL::n_priv_rows(), PFR = 4;
         auto write_out = [&](int iters, int conv) {
             static_for<0, NB>([&](auto bc) {
                 if constexpr (PL::cdeg(bc) != 1) {
@@ -261,9 +300,13 @@ lnms_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__r
                     if (post_out) post_out[frame * n + bc * Z + z] = v;
                 }
             });
+            T ring[PFR];
+            static_for<0, (PFR < NPR ? PFR : NPR)>([&](auto j) { ring[j] = load_priv(IC<PL::priv_row(j)>{}); });
             static_for<0, MB>([&](auto br) {
                 if constexpr (PL::priv_pos(br) >= 0) {
-                    const T v = priv_value(br);
+                    constexpr int j = PL::priv_row_ord(br);
+                    const T v = priv_value(br, ring[j % PFR]);
+                    if constexpr (j + PFR < NPR) ring[j % PFR] = load_priv(IC<PL::priv_row(j + PFR < NPR ? j + PFR : 0)>{});
                     const int i = priv_index(br);
                     hard_out[frame * n + i] = (uint8_t)hard_bit<1>(v);
                     if (post_out) post_out[frame * n + i] = v;
@@ -272,8 +315,16 @@ lnms_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__r
             if (z == 0) { iters_out[frame] = iters; conv_out[frame] = (uint8_t)conv; }
         };
 
-        T lp_cur = (T)0;  // channel LLR of the next private variable the sweep will need
-        if constexpr (PL::first_priv_layer() >= 0) lp_cur = load_priv(IC<(PL::first_priv_layer() >= 0 ? PL::first_priv_layer() : 0)>{});
+        // channel LLRs of the private variables the sweep needs next, requested PFS layers ahead
+        // (cyclically over the sweeps, hence a divisor of the number of such layers).  One layer
+        // ahead measured fastest: deeper queues cost registers the layers need themselves.
+        constexpr int NPL = PL::n_priv_layers();
+#ifndef LDPC_LNMS_PFS
+#define LDPC_LNMS_PFS 1
+#endif
+        constexpr int PFS = NPL == 0 || NPL % LDPC_LNMS_PFS != 0 ? 1 : LDPC_LNMS_PFS;
+        T lp_ring[PFS];
+        static_for<0, (NPL == 0 ? 0 : PFS)>([&](auto j) { lp_ring[j] = load_priv(IC<PL::priv_layer(j)>{}); });
 
         // A slot that has converged is left alone (its posteriors and check state stay as they were
         // at the successful test) and everything is written once, after the loop.
@@ -287,13 +338,19 @@ lnms_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__r
                 if (last && g.early_exit) break;  // no test after the last sweep
                 unsigned bad = 0;
                 if (!done) {
+                    T ring[PFR];
+                    static_for<0, (PFR < NPR ? PFR : NPR)>([&](auto j) { ring[j] = load_priv(IC<PL::priv_row(j)>{}); });
                     static_for<0, MB>([&](auto br) {
                         constexpr int e0 = C::row_ptr[br], D = C::row_ptr[br + 1] - e0, PP = PL::priv_pos(br);
                         unsigned par = 0;
                         unsigned zl = zb;
                         asm volatile("" : "+v"(zl));  // keep the rotated addresses out of loop-invariant hoisting
                         static_for<0, D>([&](auto p) {
-                            if constexpr (p == PP) par ^= hard_bit<1>(priv_value(br));
+                            if constexpr (p == PP) {
+                                constexpr int j = PL::priv_row_ord(br);
+                                par ^= hard_bit<1>(priv_value(br, ring[j % PFR]));
+                                if constexpr (j + PFR < NPR) ring[j % PFR] = load_priv(IC<PL::priv_row(j + PFR < NPR ? j + PFR : 0)>{});
+                            }
                             else {
                                 constexpr int bc = C::row_col[e0 + p], s = C::row_shift[e0 + p];
                                 const T v = lds_get<T>(ln_addr<LY, PL::lds_index(bc), s>(zl, zbP, zbPW));
@@ -332,9 +389,9 @@ lnms_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__r
                     if constexpr (!LY::SINGLE && PL::barrier_before(br)) __syncthreads();
                     T lp = (T)0;
                     if constexpr (PP >= 0) {
-                        lp = lp_cur;
-                        constexpr int nx = PL::next_priv_layer(br);
-                        if constexpr (nx != br) lp_cur = load_priv(IC<nx>{});
+                        constexpr int j = PL::priv_layer_ord(br);
+                        lp = lp_ring[j % PFS];
+                        if constexpr (NPL > PFS) lp_ring[j % PFS] = load_priv(IC<PL::priv_layer((j + PFS) % NPL)>{});
                     }
                     if (!done) {
                         T q[D];
@@ -367,16 +424,14 @@ lnms_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__r
                         const unsigned px = (unsigned)__popc(sq) << 31;  // sign parity of the inputs
                         const T An = g.scale * m1, Bn = g.scale * m2;
                         const T Anp = SNum<T>::flip_sign(An, px), Bnp = SNum<T>::flip_sign(Bn, px);  // parity folded in
-                        int idx = 0;
+                        unsigned minbits = 0;  // bit p: edge p holds the smallest magnitude
                         static_for<0, D>([&](auto pp) {
-                            constexpr int p = D - 1 - pp;  // descending: the first minimum wins
-                            const bool ismin = t_abs(q[p]) == m1;
-                            idx = ismin ? p : idx;
-                            if constexpr (p != PP) {
-                                const T r = SNum<T>::flip_sign(ismin ? Bnp : Anp, SNum<T>::sign_word(q[p]) & 0x80000000u);
-                                lds_put<T>(off[p], q[p] + r);
-                            }
+                            constexpr int p = D - 1 - pp;
+                            const T mag = SNum<T>::pick_min(q[p], m1, Anp, Bnp, minbits);
+                            if constexpr (p != PP)
+                                lds_put<T>(off[p], q[p] + SNum<T>::flip_sign(mag, SNum<T>::sign_word(q[p]) & 0x80000000u));
                         });
+                        const int idx = __builtin_ctz(minbits);  // the first minimum; some bit is always set
                         const unsigned wn = sq | ((unsigned)idx << 24) | px;
                         if constexpr (br < RL) { A[br] = An; B[br] = Bn; W[br] = wn; }
                         else {

@@ -33,6 +33,14 @@ template <> struct SNum<float> {
         float d; asm("v_med3_f32 %0, %1, %2, |%3|" : "=v"(d) : "v"(m1), "v"(m2), "v"(b)); return d;
     }
     __device__ static __forceinline__ Pair make(float a, float b) { return make_float2(a, b); }
+    // mag = |q| == m1 ? b : a, and the outcome of the comparison is shifted into `bits` from the
+    // right (carry-in of an add), so that no lane mask and no constant has to be kept in registers
+    __device__ static __forceinline__ float pick_min(float q, float m1, float a, float b, unsigned &bits) {
+        float mag;
+        asm("v_cmp_eq_f32_e64 vcc, |%2|, %3\n\tv_cndmask_b32_e32 %0, %4, %5, vcc\n\tv_addc_co_u32_e32 %1, vcc, %1, %1, vcc"
+            : "=&v"(mag), "+v"(bits) : "v"(q), "v"(m1), "v"(a), "v"(b) : "vcc");
+        return mag;
+    }
 };
 template <> struct SNum<double> {
     typedef double2 Pair;
@@ -53,6 +61,15 @@ template <> struct SNum<double> {
         return d;
     }
     __device__ static __forceinline__ Pair make(double a, double b) { return make_double2(a, b); }
+    __device__ static __forceinline__ double pick_min(double q, double m1, double a, double b, unsigned &bits) {
+        int lo, hi;
+        asm("v_cmp_eq_f64_e64 vcc, |%3|, %4\n\tv_cndmask_b32_e32 %0, %5, %7, vcc\n\tv_cndmask_b32_e32 %1, %6, %8, vcc\n\t"
+            "v_addc_co_u32_e32 %2, vcc, %2, %2, vcc"
+            : "=&v"(lo), "=&v"(hi), "+v"(bits)
+            : "v"(q), "v"(m1), "v"(__double2loint(a)), "v"(__double2hiint(a)), "v"(__double2loint(b)), "v"(__double2hiint(b))
+            : "vcc");
+        return __hiloint2double(hi, lo);
+    }
 };
 
 constexpr bool is_pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
