@@ -56,7 +56,7 @@ def measured_traffic(args, frames):
             rec = json.load(open(path))["workloads"].get(key)
         except (OSError, ValueError, KeyError):
             rec = None
-        if rec:
+        if rec and rec.get("early_exit", True) == (not args.fixed):
             best = rec["hbm_bytes_per_frame"] * frames
     return best
 
@@ -101,6 +101,7 @@ def main():
     ap.add_argument("--snr", type=float, default=-3.0, help="Es/N0 in dB of the synthetic channel")
     ap.add_argument("--max-iters", type=int, default=10)
     ap.add_argument("--kernel", type=int, default=0)
+    ap.add_argument("--fixed", action="store_true", help="no early exit: every frame runs max-iters updates")
     ap.add_argument("--cpu-sample", type=int, default=0, help="frames of the CPU baseline (0 = auto)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-other", action="store_true")
@@ -139,6 +140,8 @@ def main():
     if args.frames <= 0:
         args.frames = 1 << 20 if code.n <= 1024 else max(1024, (3 << 30) // (4 * code.n) // 1024 * 1024)
     cfg = config.PRESETS[args.rule].with_(max_iters=args.max_iters)
+    if args.fixed:
+        cfg = cfg.with_(early_exit=False)
     compute = np.float64 if args.dtype == "f64" else np.float32
     dec = Decoder(code)
     batch = sweep.make_batch(code, G, args.frames, args.snr, cfg, seed=[7, rank], device=device)
@@ -160,7 +163,8 @@ def main():
 
     kernel_ms = dev_ms / args.steps
     hbm_bytes = (5 * code.n + 5) * args.frames                  # f32 LLR in, u8 hard + i32 + u8 out
-    executed = stats["iterations"] + stats["not_converged"]     # failures ran max_iters, report max-1
+    # iterations actually run: failures ran max_iters but report max-1; fixed mode reports max_iters
+    executed = stats["iterations"] + (0 if args.fixed else stats["not_converged"])
     lds_bytes = lds_bytes_per_frame_iter(code, cfg.rule, 8 if args.dtype == "f64" else 4) * executed / world
     roofline = {"bound": "hbm", "achieved": hbm_bytes / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "traffic": measured_traffic(args, args.frames), "kernel": kernel_name[0],
@@ -177,9 +181,9 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"{args.code} (n={code.n}, k={k_info}) x {args.frames} frames/launch/GPU, "
                                f"rule {args.rule} ({ {'R0': 'ldpc.py decoder', 'R1': 'bpsk.py decoder', 'LNMS': 'layered min-sum, build extension'}.get(args.rule, 'sum-product') }), "
-                               f"max {args.max_iters} iterations, syndrome check per iteration, Es/N0 {args.snr} dB",
+                               f"max {args.max_iters} iterations, {'no early exit' if args.fixed else 'syndrome check per iteration'}, Es/N0 {args.snr} dB",
                    "code": args.code, "frames_per_launch_per_gpu": args.frames, "rule": args.rule,
-                   "max_iters": args.max_iters, "early_exit": True, "es_n0_db": args.snr,
+                   "max_iters": args.max_iters, "early_exit": not args.fixed, "es_n0_db": args.snr,
                    "llr_dtype": "f32", "kernel": kernel_name[0], "sharding": f"frames x{world}"},
         "mean_iters": stats["mean_iters"], "fer": stats["fer"], "ber": stats["ber"],
         "counters": {k: stats[k] for k in sweep.COUNTER_NAMES},

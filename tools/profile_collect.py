@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Turn the raw output of tools/profile_round.sh (gpurun_out/prof_<tag>/) into the summaries kept
+under profiles/: the kernel-trace statistics of each bench workload (decoder kernels and the ten
+largest others) and the HBM traffic of the decode kernel from the FETCH_SIZE / WRITE_SIZE passes.
+
+    python tools/profile_collect.py r01b
+"""
+import csv
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1]
+src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+dst = os.path.join(ROOT, "profiles")
+WORKLOADS = {"ccsds_r0_f64": "ccsds512/R0/f64/f32llr", "bg1_lnms_f32": "nr_bg1_z384/LNMS/f32/f32llr"}
+
+
+def decoder_kernel(name):
+    return "ldpc::" in name and "count_errors" not in name
+
+
+for wl in WORKLOADS:
+    rows = list(csv.DictReader(open(os.path.join(src, f"stats_{wl}", "t_kernel_stats.csv"))))
+    keep = [r for r in rows if decoder_kernel(r["Name"])] + [r for r in rows if not decoder_kernel(r["Name"])][:10]
+    out = os.path.join(dst, f"{tag}_{wl}_kernel_stats.csv")
+    with open(out, "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+        w.writeheader()
+        for r in keep:
+            r = dict(r)
+            if len(r["Name"]) > 200:
+                r["Name"] = r["Name"][:200] + "..."
+            w.writerow(r)
+    print("wrote", out)
+
+traffic = {"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over `python bench.py --steps 2 "
+                   "--warmup 1 --no-other --no-cpu [workload flags]`; values in KiB per dispatch of the decode kernel "
+                   "(mean over its dispatches).  On gfx950 FETCH_SIZE reports half of the bytes actually fetched "
+                   "(128-byte requests tallied as 64), so the read side is doubled; WRITE_SIZE is taken as is.",
+           "workloads": {}}
+for wl, key in WORKLOADS.items():
+    vals = {}
+    for ctr, d in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
+        rows = list(csv.DictReader(open(os.path.join(src, f"{d}_{wl}", "t_counter_collection.csv"))))
+        per = {}
+        for r in rows:
+            if decoder_kernel(r["Kernel_Name"]) and r["Counter_Name"] == ctr:
+                per[r["Dispatch_Id"]] = per.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
+        vals[ctr] = sum(per.values()) / len(per)
+    bench = json.load(open(os.path.join(src, f"fetch_{wl}.json")))
+    frames = bench["config"]["frames_per_launch_per_gpu"]
+    total = (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024
+    traffic["workloads"][key] = {
+        "frames": frames, "FETCH_SIZE_KiB": vals["FETCH_SIZE"], "WRITE_SIZE_KiB": vals["WRITE_SIZE"],
+        "hbm_bytes_corrected": total, "hbm_bytes_per_frame": total / frames,
+        "algorithmic_bytes_per_frame": bench["roofline"]["bytes_per_frame"],
+        "early_exit": bench["config"]["early_exit"], "kernel": bench["config"]["kernel"]}
+out = os.path.join(dst, f"{tag}_hbm_traffic.json")
+json.dump(traffic, open(out, "w"), indent=1)
+print("wrote", out)
+print(json.dumps(traffic["workloads"], indent=1))

@@ -1,0 +1,31 @@
+#!/bin/bash
+# Profiles of the bench workloads on the GPU box: kernel-trace statistics and HBM traffic counters.
+#   gpurun -- 'bash tools/profile_round.sh r01'
+# Raw output goes to gpurun_out/prof_<tag>/; tools/profile_collect.py turns it into profiles/.
+set -e -o pipefail
+TAG=${1:-r01}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+B=$GRAFT_REPO_ROOT/bench.py
+run_stats() {  # name, bench args...
+    local name=$1; shift
+    timeout -k 10 240 rocprofv3 --kernel-trace --stats -d "$OUT/$name" -o t --output-format csv -- \
+        python3 "$B" --steps 5 --warmup 2 --no-other --no-cpu "$@" > "$OUT/$name.json" 2> "$OUT/$name.err"
+}
+run_pmc() {  # name, counter, bench args...
+    local name=$1 ctr=$2; shift 2
+    timeout -s KILL 200 rocprofv3 --pmc "$ctr" -d "$OUT/$name" -o t --output-format csv -- \
+        python3 "$B" --steps 2 --warmup 1 --no-other --no-cpu "$@" > "$OUT/$name.json" 2> "$OUT/$name.err"
+}
+run_stats stats_ccsds_r0_f64
+echo "stats ccsds done"
+run_stats stats_bg1_lnms_f32 --code nr_bg1_z384 --rule LNMS --dtype f32 --frames 16384 --fixed
+echo "stats bg1 done"
+run_pmc fetch_ccsds_r0_f64 FETCH_SIZE
+run_pmc write_ccsds_r0_f64 WRITE_SIZE
+echo "pmc ccsds done"
+run_pmc fetch_bg1_lnms_f32 FETCH_SIZE --code nr_bg1_z384 --rule LNMS --dtype f32 --frames 16384 --fixed
+run_pmc write_bg1_lnms_f32 WRITE_SIZE --code nr_bg1_z384 --rule LNMS --dtype f32 --frames 16384 --fixed
+echo "pmc bg1 done"
+ls "$OUT"
