@@ -15,6 +15,7 @@ error counters.
 Rank 0 prints one JSON line.  Beside the headline value it carries
   roofline      algorithmic HBM bytes per launch / measured kernel time, against 8 TB/s
   lds_roofline  algorithmic LDS bytes of the executed iterations against the nominal LDS rate
+  valu_roofline vector instructions issued (counter pass on file) against the nominal issue rate
   cpu_baseline  the CPU restatement (oracle/bp_oracle.c, OpenMP) timed on a bounded sample of the
                 same LLRs on this host, which doubles as a parity check of that sample
   other         secondary workloads (early exit at an operating SNR, float32, rule R1, NR BG1
@@ -59,6 +60,27 @@ def measured_traffic(args, frames):
         if rec and rec.get("early_exit", True) == (not args.fixed):
             best = rec["hbm_bytes_per_frame"] * frames
     return best
+
+
+def valu_roofline(args, executed_frame_iters, kernel_ms):
+    """Vector-issue bound: wave-instructions per second against one instruction per SIMD every 4
+    cycles (256 CUs x 4 SIMDs x 2.4 GHz / 4).  The instruction count per frame-iteration comes from
+    the SQ_INSTS_VALU pass on file for this workload (profiles/*_sq_counters.json)."""
+    key = f"{args.code}/{args.rule}/{args.dtype}/f32llr"
+    per = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sq_counters.json"))):
+        try:
+            rec = json.load(open(path))["workloads"].get(key)
+        except (OSError, ValueError, KeyError):
+            rec = None
+        if rec and rec.get("early_exit", True) == (not args.fixed):
+            per = rec["valu_wave_instructions_per_frame_iteration"]
+    if per is None:
+        return None
+    peak = 256 * 4 * 2.4e9 / 4 / 1e9
+    achieved = per * executed_frame_iters / (kernel_ms * 1e-3) / 1e9
+    return {"bound": "valu", "achieved": achieved, "peak": peak, "unit": "G wave-instructions/s",
+            "frac": achieved / peak, "valu_per_frame_iteration": per}
 
 
 def timed_steps(fn, steps, warmup, torch, dist, world):
@@ -189,6 +211,9 @@ def main():
         "counters": {k: stats[k] for k in sweep.COUNTER_NAMES},
         "roofline": roofline, "lds_roofline": lds,
     }
+    vr = valu_roofline(args, executed / world, kernel_ms)
+    if vr:
+        out["valu_roofline"] = vr
 
     if rank == 0 and world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(code, cfg, batch, k_info, args)

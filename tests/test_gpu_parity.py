@@ -141,3 +141,25 @@ def test_fixed_iterations_mode(c_oracle):
             assert np.array_equal(res.converged, ec)
             assert np.array_equal(res.hard, eh)
             assert np.array_equal(res.posterior, ep)
+
+
+def test_wifi648_64k_frames_min_sum_bit_exact(c_oracle):
+    """The 802.11n (648,324) code, 65 536 frames in one launch, extrinsic min-sum with 10
+    iterations, random codewords from this build's generator, float32-representable LLRs:
+    every frame's hard decisions, iteration count and flag equal the CPU restatement's."""
+    from ldpc_amd import config
+    cfg = config.R1.with_(max_iters=10, num_refresh_vars=-1)
+    code = codes.load_packaged("wifi648")
+    G = codes.load_packaged_generator("wifi648")
+    rng = np.random.default_rng([64, 648])
+    B = 65536
+    cw = codes.encode(G, rng.integers(0, 2, size=(B, G.shape[0])))
+    ebn0 = 2.0
+    sigma2 = 1.0 / (2.0 * 0.5 * 10 ** (ebn0 / 10))                  # rate 1/2
+    y = (1.0 - 2.0 * cw) + np.sqrt(sigma2) * rng.standard_normal(cw.shape)
+    L = (2.0 * y / sigma2).astype(np.float32).astype(np.float64)
+    eh, ei, ec, _ = c_oracle.c_decode(code, cfg, L, want_posterior=False)
+    res = decoder_for("wifi648").decode(L.astype(np.float32), cfg, compute_dtype=np.float64)
+    assert res.kernel == "spec_r1_f64"
+    assert np.array_equal(res.converged, ec) and np.array_equal(res.iters, ei) and np.array_equal(res.hard, eh)
+    assert 0.2 * B < ec.sum() < B

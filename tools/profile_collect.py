@@ -57,6 +57,34 @@ for wl, key in WORKLOADS.items():
         "hbm_bytes_corrected": total, "hbm_bytes_per_frame": total / frames,
         "algorithmic_bytes_per_frame": bench["roofline"]["bytes_per_frame"],
         "early_exit": bench["config"]["early_exit"], "kernel": bench["config"]["kernel"]}
+# instruction counters of the decode kernel (one more pass), per dispatch
+sq = {"note": "rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAVES SQ_WAVE_CYCLES "
+              "SQ_BUSY_CU_CYCLES SQ_WAIT_ANY over the same bench command; sums over the device per dispatch of the "
+              "decode kernel (mean over its dispatches); SQ_WAVE_CYCLES and SQ_WAIT_ANY count in units of 4 cycles.",
+      "workloads": {}}
+for wl, key in WORKLOADS.items():
+    path = os.path.join(src, f"sq_{wl}", "t_counter_collection.csv")
+    if not os.path.exists(path):
+        continue
+    per = {}
+    for r in csv.DictReader(open(path)):
+        if decoder_kernel(r["Kernel_Name"]):
+            d = per.setdefault(r["Dispatch_Id"], {})
+            d[r["Counter_Name"]] = d.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+    mean = {c: sum(d[c] for d in per.values()) / len(per) for c in next(iter(per.values()))}
+    bench = json.load(open(os.path.join(src, f"sq_{wl}.json")))
+    frames = bench["config"]["frames_per_launch_per_gpu"]
+    executed = bench["counters"]["iterations"] + (0 if not bench["config"]["early_exit"] else bench["counters"]["not_converged"])
+    mean.update({"frames": frames, "executed_frame_iterations": executed, "kernel": bench["config"]["kernel"],
+                 "early_exit": bench["config"]["early_exit"],
+                 "valu_wave_instructions_per_frame_iteration": mean["SQ_INSTS_VALU"] / executed})
+    sq["workloads"][key] = mean
+if sq["workloads"]:
+    out = os.path.join(dst, f"{tag}_sq_counters.json")
+    json.dump(sq, open(out, "w"), indent=1)
+    print("wrote", out)
+    print(json.dumps(sq["workloads"], indent=1))
+
 out = os.path.join(dst, f"{tag}_hbm_traffic.json")
 json.dump(traffic, open(out, "w"), indent=1)
 print("wrote", out)

@@ -15,7 +15,7 @@ run_stats() {  # name, bench args...
 }
 run_pmc() {  # name, counter, bench args...
     local name=$1 ctr=$2; shift 2
-    timeout -s KILL 200 rocprofv3 --pmc "$ctr" -d "$OUT/$name" -o t --output-format csv -- \
+    timeout -s KILL 200 rocprofv3 --pmc $ctr -d "$OUT/$name" -o t --output-format csv -- \
         python3 "$B" --steps 2 --warmup 1 --no-other --no-cpu "$@" > "$OUT/$name.json" 2> "$OUT/$name.err"
 }
 run_stats stats_ccsds_r0_f64
@@ -28,4 +28,8 @@ echo "pmc ccsds done"
 run_pmc fetch_bg1_lnms_f32 FETCH_SIZE --code nr_bg1_z384 --rule LNMS --dtype f32 --frames 16384 --fixed
 run_pmc write_bg1_lnms_f32 WRITE_SIZE --code nr_bg1_z384 --rule LNMS --dtype f32 --frames 16384 --fixed
 echo "pmc bg1 done"
+SQ="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_ANY"
+run_pmc sq_ccsds_r0_f64 "$SQ"
+run_pmc sq_bg1_lnms_f32 "$SQ" --code nr_bg1_z384 --rule LNMS --dtype f32 --frames 16384 --fixed
+echo "sq counters done"
 ls "$OUT"
