@@ -10,8 +10,9 @@
 //     check's state when hard decisions are needed;
 //   * the previous messages of a check, compressed to three words: A = scale * m1, B = scale * m2
 //     (smallest / second smallest input magnitude) and W = position of the smallest input (bits
-//     24-28) | sign parity of the inputs (bit 31) | sign of each input (low bits, first edge
-//     highest).  The first RL block rows keep them in registers, the others in LDS.
+//     24-28) | sign parity of the inputs (bit 31) | hard decision of the private variable (bit
+//     30) | sign of each input (low bits, first edge highest).  The first RL block rows keep
+//     them in registers, the others in LDS.
 // A layer reads P (rotated), subtracts the old message, updates (m1, m2, signs), adds the new
 // message and writes P back to the same place.  All checks of a block row touch distinct
 // variables (blocks that are sums of two circulants are not supported), so the block-parallel
@@ -276,6 +277,18 @@ lnms_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__r
             if constexpr (s != 0) o += (unsigned)z + s >= (unsigned)Z ? (unsigned)(s - Z) : (unsigned)s;
             return (T)lf[o + (unsigned)(bc * Z)] + (T)0;
         };
+        // Bit 30 of W holds the hard decision of the layer's private variable whenever a syndrome
+        // test may follow (early exit: always; else after the last sweep), so that the test needs
+        // no channel LLRs.  Before the first sweep that decision is the channel's.
+        if (g.early_exit) {
+            static_for<0, MB>([&](auto br) {
+                if constexpr (PL::is_priv_layer(br)) {
+                    const unsigned hb = hard_bit<1>(load_priv(br)) << 30;
+                    if constexpr (br < RL) W[br] = hb;
+                    else if (lane_on) lds_put<unsigned>(stW + LY::state_off(br - RL), hb);
+                }
+            });
+        }
         // posterior L + r of that variable, r rebuilt from the check's state
         auto priv_value = [&](auto br, T l) -> T {
             constexpr int D = PL::rdeg(br), p = PL::priv_pos(br);
@@ -338,23 +351,27 @@ lnms_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__r
                 if (last && g.early_exit) break;  // no test after the last sweep
                 unsigned bad = 0;
                 if (!done) {
-                    T ring[PFR];
-                    static_for<0, (PFR < NPR ? PFR : NPR)>([&](auto j) { ring[j] = load_priv(IC<PL::priv_row(j)>{}); });
                     static_for<0, MB>([&](auto br) {
                         constexpr int e0 = C::row_ptr[br], D = C::row_ptr[br + 1] - e0, PP = PL::priv_pos(br);
-                        unsigned par = 0;
                         unsigned zl = zb;
                         asm volatile("" : "+v"(zl));  // keep the rotated addresses out of loop-invariant hoisting
-                        static_for<0, D>([&](auto p) {
-                            if constexpr (p == PP) {
-                                constexpr int j = PL::priv_row_ord(br);
-                                par ^= hard_bit<1>(priv_value(br, ring[j % PFR]));
-                                if constexpr (j + PFR < NPR) ring[j % PFR] = load_priv(IC<PL::priv_row(j + PFR < NPR ? j + PFR : 0)>{});
-                            }
-                            else {
+                        T v[D > 0 ? D : 1];
+                        static_for<0, D>([&](auto p) {  // all reads of the row first, then their signs
+                            if constexpr (p != PP) {
                                 constexpr int bc = C::row_col[e0 + p], s = C::row_shift[e0 + p];
-                                const T v = lds_get<T>(ln_addr<LY, PL::lds_index(bc), s>(zl, zbP, zbPW));
-                                par ^= hard_bit<1>(v);
+                                v[p] = lds_get<T>(ln_addr<LY, PL::lds_index(bc), s>(zl, zbP, zbPW));
+                            }
+                        });
+                        unsigned par = 0;
+                        static_for<0, D>([&](auto p) {
+                            if constexpr (p != PP) par ^= hard_bit<1>(v[p]);
+                            else if constexpr (D >= 2) {
+                                T a, b;
+                                unsigned w;
+                                load_state(br, a, b, w);
+                                par ^= (w >> 30) & 1u;
+                            } else {
+                                par ^= hard_bit<1>(load_priv(br));  // a check of degree one
                             }
                         });
                         bad |= par;
@@ -383,6 +400,7 @@ lnms_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__r
                 }
             }
             // ---- one sweep over the layers
+            const bool want_bits = g.early_exit || t == g.max_iters - 1;
             static_for<0, MB>([&](auto br) {
                 constexpr int e0 = C::row_ptr[br], D = C::row_ptr[br + 1] - e0, PP = PL::priv_pos(br);
                 if constexpr (D >= 2) {
@@ -425,14 +443,17 @@ lnms_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__r
                         const T An = g.scale * m1, Bn = g.scale * m2;
                         const T Anp = SNum<T>::flip_sign(An, px), Bnp = SNum<T>::flip_sign(Bn, px);  // parity folded in
                         unsigned minbits = 0;  // bit p: edge p holds the smallest magnitude
+                        unsigned privbit = 0;
                         static_for<0, D>([&](auto pp) {
                             constexpr int p = D - 1 - pp;
                             const T mag = SNum<T>::pick_min(q[p], m1, Anp, Bnp, minbits);
                             if constexpr (p != PP)
                                 lds_put<T>(off[p], q[p] + SNum<T>::flip_sign(mag, SNum<T>::sign_word(q[p]) & 0x80000000u));
+                            else if (want_bits)
+                                privbit = hard_bit<1>(q[p] + SNum<T>::flip_sign(mag, SNum<T>::sign_word(q[p]) & 0x80000000u)) << 30;
                         });
                         const int idx = __builtin_ctz(minbits);  // the first minimum; some bit is always set
-                        const unsigned wn = sq | ((unsigned)idx << 24) | px;
+                        const unsigned wn = sq | ((unsigned)idx << 24) | px | privbit;
                         if constexpr (br < RL) { A[br] = An; B[br] = Bn; W[br] = wn; }
                         else {
                             lds_put<T>(stA + LY::state_off(br - RL), An);
