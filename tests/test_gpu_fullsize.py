@@ -1,0 +1,118 @@
+"""Parity at the full batch sizes of the bench workloads, through properties that do not need a
+CPU decode of every frame: converged frames are codewords, noiseless codewords come back after
+the minimum number of iterations, results do not depend on the batch a frame travels in, and a
+leading slice of the big batch is identical to the CPU restatement."""
+import numpy as np
+import pytest
+
+from ldpc_amd import codes, config
+
+pytestmark = pytest.mark.gpu
+
+
+def _syndrome_weight(code, hard_dev, torch):
+    """Number of unsatisfied checks per frame, on the device (dense H, exact small integers)."""
+    H = torch.as_tensor(code.dense(), dtype=torch.float32, device=hard_dev.device)
+    out = torch.empty(hard_dev.shape[0], dtype=torch.int64, device=hard_dev.device)
+    step = 1 << 17
+    for a in range(0, hard_dev.shape[0], step):
+        s = torch.remainder(hard_dev[a:a + step].to(torch.float32) @ H.T, 2.0)
+        out[a:a + step] = s.sum(dim=1).to(torch.int64)
+    return out
+
+
+@pytest.mark.parametrize("rule,dtype", [("R0", np.float64), ("R1", np.float64), ("R0", np.float32)])
+def test_ccsds_one_million_frames(rule, dtype, c_oracle):
+    import torch
+    from ldpc_amd import sweep
+    from ldpc_amd.decoder import Decoder
+    code = codes.load_packaged("ccsds512")
+    G = codes.load_packaged_generator("ccsds512")
+    cfg = config.PRESETS[rule].with_(max_iters=10)
+    dev = torch.device("cuda", 0)
+    dec = Decoder(code)
+    frames = 1 << 20
+    batch = sweep.make_batch(code, G, frames, 1.0, cfg, seed=[21, cfg.rule], device=dev)
+    sweep.decode_batch(dec, batch, cfg, compute_dtype=dtype)
+    torch.cuda.synchronize()
+    conv = batch.converged.bool()
+    assert 0.9 * frames < int(conv.sum()) < frames                      # Es/N0 1 dB: a few frames fail
+    # every frame flagged as converged is a codeword, and failures report max_iters - 1
+    assert int(_syndrome_weight(code, batch.hard, torch)[conv].max()) == 0
+    assert bool((batch.iters[~conv] == cfg.max_iters - 1).all())
+    assert int(batch.iters.min()) >= (1 if rule == "R0" else 0)        # ldpc.py:158,165: R0 never stops at 0
+    # a frame's result does not depend on the batch around it
+    pick = torch.randperm(frames, device=dev, generator=torch.Generator(device=dev).manual_seed(3))[:8192]
+    sub = sweep.DeviceBatch(batch.llr[pick].contiguous(), batch.ref[pick].contiguous(),
+                            torch.empty((8192, code.n), dtype=torch.uint8, device=dev),
+                            torch.empty((8192,), dtype=torch.int32, device=dev),
+                            torch.empty((8192,), dtype=torch.uint8, device=dev),
+                            torch.zeros((5,), dtype=torch.int64, device=dev))
+    sweep.decode_batch(dec, sub, cfg, compute_dtype=dtype)
+    torch.cuda.synchronize()
+    assert torch.equal(sub.hard, batch.hard[pick]) and torch.equal(sub.iters, batch.iters[pick])
+    assert torch.equal(sub.converged, batch.converged[pick])
+    if dtype == np.float64:  # the head of the batch against the CPU restatement, bit for bit
+        L = batch.llr[:16384].cpu().numpy().astype(np.float64)
+        eh, ei, ec, _ = c_oracle.c_decode(code, cfg, L, want_posterior=False)
+        assert np.array_equal(eh, batch.hard[:16384].cpu().numpy())
+        assert np.array_equal(ei, batch.iters[:16384].cpu().numpy())
+        assert np.array_equal(ec, batch.converged[:16384].cpu().numpy().astype(bool))
+    # error counters agree with a recount on the host side of the same outputs
+    sweep.count_errors(dec, batch)
+    torch.cuda.synchronize()
+    c = batch.counters.cpu().numpy()
+    assert c[0] == frames and c[1] == frames - int(conv.sum())
+    assert c[3] == int((batch.hard != batch.ref).sum())
+
+
+def test_ccsds_noiseless_round_trip_one_million_frames():
+    """encode -> (no noise) -> decode: every frame returns its codeword after one R0 iteration
+    (the iteration-0 test on raw LLRs never passes, ldpc.py:158,165) and zero R1 iterations."""
+    import torch
+    from ldpc_amd import sweep
+    from ldpc_amd.decoder import Decoder
+    code = codes.load_packaged("ccsds512")
+    G = codes.load_packaged_generator("ccsds512")
+    dev = torch.device("cuda", 0)
+    dec = Decoder(code)
+    frames = 1 << 20
+    for rule, iters in (("R0", 1), ("R1", 0)):
+        cfg = config.PRESETS[rule].with_(max_iters=10)
+        batch = sweep.make_batch(code, G, frames, 60.0, cfg, seed=[22], device=dev)   # 60 dB: noise ~ 1e-3
+        sweep.decode_batch(dec, batch, cfg, compute_dtype=np.float64)
+        torch.cuda.synchronize()
+        assert bool(batch.converged.bool().all()) and bool((batch.iters == iters).all())
+        assert torch.equal(batch.hard, batch.ref)
+
+
+def test_bg1_layered_full_batch(c_oracle):
+    import torch
+    from ldpc_amd import sweep
+    from ldpc_amd.decoder import Decoder
+    code = codes.load_packaged("nr_bg1_z384")
+    dev = torch.device("cuda", 0)
+    dec = Decoder(code)
+    frames = 16384
+    cfg = config.LNMS.with_(max_iters=10)
+    batch = sweep.make_batch(code, None, frames, -3.0, cfg, seed=[23], device=dev)
+    sweep.decode_batch(dec, batch, cfg, compute_dtype=np.float32)
+    torch.cuda.synchronize()
+    conv = batch.converged.bool()
+    assert int(conv.sum()) > 0.99 * frames
+    # the all-zero codeword was sent: converged frames are codewords, here the right one
+    hard = batch.hard.cpu().numpy()
+    assert code.is_codeword(hard[:2048][conv[:2048].cpu().numpy()]).all()
+    assert int(batch.hard[conv].sum()) == 0
+    # fixed-work mode runs the same sweeps: frames that converged keep their decisions
+    fixed = cfg.with_(early_exit=False)
+    again = sweep.make_batch(code, None, frames, -3.0, cfg, seed=[23], device=dev)
+    sweep.decode_batch(dec, again, fixed, compute_dtype=np.float32)
+    torch.cuda.synchronize()
+    assert bool((again.iters == 10).all())
+    assert int(again.converged.sum()) > 0.99 * frames and int(again.hard[again.converged.bool()].sum()) == 0
+    # head of the batch against the CPU restatement in float, bit for bit
+    L = batch.llr[:192].cpu().numpy().astype(np.float64)
+    eh, ei, ec, _ = c_oracle.c_decode_lnms(code, cfg, L, use_float=True, want_posterior=False)
+    assert np.array_equal(eh, hard[:192]) and np.array_equal(ei, batch.iters[:192].cpu().numpy())
+    assert np.array_equal(ec, conv[:192].cpu().numpy())
