@@ -42,6 +42,115 @@ __device__ inline double t_fmod(double x, double y) { return fmod(x, y); }
 template <typename T>
 __device__ inline T clip(T x, T lo, T hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
+// ---------------------------------------------------------------------------------------------
+// Transcendentals of the sum-product rules.  The library versions spend 60-150 instructions per
+// call on cases these decoders never produce (huge arguments, denormals, exact rounding); the
+// versions below are plain range reduction + polynomial, a few ulp in double and hardware
+// exp2/log2 in float.  The parity bar for these rules is 1e-4 relative on posteriors with
+// identical decisions and iteration counts, which is many orders of magnitude looser.
+// Compile with -DLDPC_LIBM_TRANSCENDENTALS to get the library functions back.
+#ifndef LDPC_LIBM_TRANSCENDENTALS
+// a / b, b normal and not tiny: reciprocal seed + two Newton steps + one residual correction
+__device__ inline double f_div(double a, double b) {
+    double r = __builtin_amdgcn_rcp(b);
+    r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+    const double q = a * r;
+    return __builtin_fma(__builtin_fma(-b, q, a), r, q);
+}
+__device__ inline float f_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+// e^x for |x| < 700
+__device__ inline double f_exp(double x) {
+    const double n = __builtin_rint(x * 1.4426950408889634);
+    double r = __builtin_fma(-n, 6.93147180369123816490e-01, x);
+    r = __builtin_fma(-n, 1.90821492927058770002e-10, r);
+    double p = 2.08767569878680989792e-09;  // 1/12!
+    p = __builtin_fma(p, r, 2.50521083854417187751e-08);
+    p = __builtin_fma(p, r, 2.75573192239858906526e-07);
+    p = __builtin_fma(p, r, 2.75573192239858906526e-06);
+    p = __builtin_fma(p, r, 2.48015873015873015873e-05);
+    p = __builtin_fma(p, r, 1.98412698412698412698e-04);
+    p = __builtin_fma(p, r, 1.38888888888888888889e-03);
+    p = __builtin_fma(p, r, 8.33333333333333333333e-03);
+    p = __builtin_fma(p, r, 4.16666666666666666667e-02);
+    p = __builtin_fma(p, r, 1.66666666666666666667e-01);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    return __builtin_ldexp(p, (int)n);
+}
+__device__ inline float f_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504f); }
+// log(x), x normal and positive
+__device__ inline double f_log(double x) {
+    double m = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1)
+    int e = __builtin_amdgcn_frexp_exp(x);
+    const bool low = m < 0.70710678118654752440;
+    m = low ? m + m : m;
+    e = low ? e - 1 : e;
+    const double s = f_div(m - 1.0, m + 1.0);  // |s| <= 0.1716
+    const double z = s * s;
+    double p = 1.0 / 23.0;
+    p = __builtin_fma(p, z, 1.0 / 21.0);
+    p = __builtin_fma(p, z, 1.0 / 19.0);
+    p = __builtin_fma(p, z, 1.0 / 17.0);
+    p = __builtin_fma(p, z, 1.0 / 15.0);
+    p = __builtin_fma(p, z, 1.0 / 13.0);
+    p = __builtin_fma(p, z, 1.0 / 11.0);
+    p = __builtin_fma(p, z, 1.0 / 9.0);
+    p = __builtin_fma(p, z, 1.0 / 7.0);
+    p = __builtin_fma(p, z, 1.0 / 5.0);
+    p = __builtin_fma(p, z, 1.0 / 3.0);
+    p = p * z;                                  // log(m) = 2 s (1 + p)
+    const double lm = __builtin_fma(s + s, p, s + s);
+    const double de = (double)e;
+    return __builtin_fma(de, 6.93147180369123816490e-01, __builtin_fma(de, 1.90821492927058770002e-10, lm));
+}
+__device__ inline float f_log(float x) { return __builtin_amdgcn_logf(x) * 0.693147181f; }
+// tanh: odd series below 2^-6 (double) / 0.06 (float), (1 - e^-2|x|) / (1 + e^-2|x|) above
+__device__ inline double f_tanh(double x) {
+    const double ax = __builtin_fabs(x), x2 = x * x;
+    const double small = x * __builtin_fma(x2, __builtin_fma(x2, __builtin_fma(x2, -17.0 / 315.0, 2.0 / 15.0), -1.0 / 3.0), 1.0);
+    const double e = f_exp(-2.0 * (ax < 40.0 ? ax : 40.0));
+    const double big = __builtin_copysign(f_div(1.0 - e, 1.0 + e), x);
+    return ax < 0.015625 ? small : big;
+}
+__device__ inline float f_tanh(float x) {
+    const float ax = __builtin_fabsf(x), x2 = x * x;
+    const float small = x * __builtin_fmaf(x2, __builtin_fmaf(x2, 2.0f / 15.0f, -1.0f / 3.0f), 1.0f);
+    const float e = f_exp(-2.0f * (ax < 20.0f ? ax : 20.0f));
+    const float big = __builtin_copysignf(f_div(1.0f - e, 1.0f + e), x);
+    return ax < 0.06f ? small : big;
+}
+// atanh for |x| < 1: odd series below 2^-6 (double) / 0.06 (float), log((1 + |x|) / (1 - |x|)) / 2 above
+__device__ inline double f_atanh(double x) {
+    const double ax = __builtin_fabs(x), x2 = x * x;
+    double p = 1.0 / 9.0;
+    p = __builtin_fma(p, x2, 1.0 / 7.0);
+    p = __builtin_fma(p, x2, 1.0 / 5.0);
+    p = __builtin_fma(p, x2, 1.0 / 3.0);
+    const double small = __builtin_fma(x * x2, p, x);
+    const double big = __builtin_copysign(0.5 * f_log(f_div(1.0 + ax, 1.0 - ax)), x);
+    return ax < 0.015625 ? small : big;
+}
+__device__ inline float f_atanh(float x) {
+    const float ax = __builtin_fabsf(x), x2 = x * x;
+    const float small = __builtin_fmaf(x * x2, __builtin_fmaf(x2, 0.2f, 1.0f / 3.0f), x);
+    const float big = __builtin_copysignf(0.5f * f_log(f_div(1.0f + ax, 1.0f - ax)), x);
+    return ax < 0.06f ? small : big;
+}
+#else
+__device__ inline double f_div(double a, double b) { return a / b; }
+__device__ inline float f_div(float a, float b) { return a / b; }
+__device__ inline double f_exp(double x) { return exp(x); }
+__device__ inline float f_exp(float x) { return expf(x); }
+__device__ inline double f_log(double x) { return log(x); }
+__device__ inline float f_log(float x) { return logf(x); }
+__device__ inline double f_tanh(double x) { return tanh(x); }
+__device__ inline float f_tanh(float x) { return tanhf(x); }
+__device__ inline double f_atanh(double x) { return atanh(x); }
+__device__ inline float f_atanh(float x) { return atanhf(x); }
+#endif
+
 // Running state of a min-sum check node: smallest and second smallest magnitude, position of the
 // smallest, sign bits.  Equivalent to the reference's per-target min over the other inputs
 // (ldpc.py:184-187, bpsk.py:221-230): the target holding the smallest magnitude gets the second
@@ -85,21 +194,21 @@ template <typename T>
 __device__ inline T spa_tanh_half(T q, T clip_arg) {
     T a = q / (T)2;
     if (clip_arg > (T)0) a = clip(a, -clip_arg, clip_arg);
-    return t_tanh(a);
+    return f_tanh(a);
 }
 // R2: 2*arctanh(clip(prod)) (bpsk.py:337-339); R3: 0.85*2*arctanh(clip(prod)) (channel.py:473-474)
 template <typename T>
 __device__ inline T spa_message(T prod, T clip_prod, T scale, bool scaled) {
     T lim = clip_prod < Lim<T>::below_one() ? clip_prod : Lim<T>::below_one();
     prod = clip(prod, -lim, lim);
-    return scaled ? (scale * (T)2) * t_atanh(prod) : (T)2 * t_atanh(prod);
+    return scaled ? (scale * (T)2) * f_atanh(prod) : (T)2 * f_atanh(prod);
 }
 // phi(x) = log((e^x + 1) / (e^x - 1)) on x clipped to [1e-12, 100] (channel.py:392-398)
 template <typename T>
 __device__ inline T phi(T x) {
     x = clip(x, (T)1e-12, Lim<T>::phi_arg_max());
-    T ex = t_exp(x);
-    return t_log((ex + (T)1) / (ex - (T)1));
+    T ex = f_exp(x);
+    return f_log(f_div(ex + (T)1, ex - (T)1));
 }
 // R4 message magnitude: phi(clip(sum of phi, 1e-12, 20)) (channel.py:347-349)
 template <typename T>
