@@ -37,9 +37,11 @@ extern "C" {
  * schedules); a build extension for the large 5G codes whose flooding messages do not fit on
  * chip.  Checks are visited in ascending order; each takes q = P - r_old from the current
  * posteriors P, forms r_new = scale * min-of-the-others * sign-product-of-the-others and writes
- * P = q + r_new back at once.  Iteration count, syndrome test at the top of each iteration, LLR
- * polarity and hard decision are those of R1.  Circulant codes without double-circulant blocks
- * only (all checks of a block row then touch distinct variables).
+ * P = q + r_new back at once.  A variable that takes part in one check only sends that check its
+ * channel LLR itself (its exact extrinsic value).  Iteration count, syndrome test at the top of
+ * each iteration, LLR polarity and hard decision are those of R1.  Served for the packaged
+ * circulant codes without double-circulant blocks (all checks of a block row then touch distinct
+ * variables) and with at most one degree-one variable per check; LDPC_ERR_UNSUPPORTED otherwise.
  */
 #define LDPC_RULE_LNMS 5
 

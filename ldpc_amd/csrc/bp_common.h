@@ -73,6 +73,10 @@ hipError_t launch_spec(int spec_id, const ldpc_decode_config &cfg, int compute_d
 // decode_lnms.hip: row-layered min-sum, specialised for the packaged codes (same spec_id)
 hipError_t launch_spec_lnms(int spec_id, const ldpc_decode_config &cfg, int compute_dtype, const Launch &io,
                             int num_cus, const char **kernel_name, bool *supported);
+// decode_qc_lnms.hip: the same rule for any circulant code, base graph in device tables
+hipError_t launch_qc_lnms(const QcDev &code, const ldpc_decode_config &cfg, int compute_dtype, const Launch &io,
+                          int num_cus, void **workspace, size_t *workspace_bytes, const char **kernel_name,
+                          bool *supported);
 // count_errors.hip
 hipError_t launch_count_errors(const uint8_t *hard, const uint8_t *ref, long long ref_stride,
                                const int *iters, const uint8_t *conv, long long frames, int n,

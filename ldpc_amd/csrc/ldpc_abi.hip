@@ -40,6 +40,7 @@ struct ldpc_code {
     int *d_ints = nullptr;  // one allocation: row_ptr | col_idx | col_ptr | csc_edge
     CsrDev csr{};
     bool has_qc = false;
+    bool qc_pairs = false;  // some block is the sum of two circulants
     int spec_id = -1;       // compiled-in specialisation of this code, if any
     QcDev qc{};
     int *d_qc = nullptr;    // one allocation: row_ptr | row_info | col_ptr | col_info
@@ -176,6 +177,7 @@ extern "C" int32_t ldpc_code_attach_qc(ldpc_code *c, int32_t mb, int32_t nb, int
     {
         std::vector<int> fill(col_ptr.begin(), col_ptr.end() - 1);
         std::vector<int> last_row(nb, -1), run(nb, 0);
+        c->qc_pairs = false;
         for (int e = 0; e < Eb; ++e) {  // ascending block row inside each column
             const int bc = ec[e], k = fill[bc]++;
             col_info[k] = ((unsigned)e << 16) | (unsigned)es[e];
@@ -185,6 +187,7 @@ extern "C" int32_t ldpc_code_attach_qc(ldpc_code *c, int32_t mb, int32_t nb, int
                     return fail(LDPC_ERR_UNSUPPORTED, "block (%d,%d) is the sum of more than two circulants", er[e], bc);
                 col_info[k - 1] |= 0x8000u;
                 colr_info[k - 1] |= 0x8000u;
+                c->qc_pairs = true;
             } else {
                 run[bc] = 1;
             }
@@ -274,9 +277,17 @@ extern "C" int32_t ldpc_decode_batch(ldpc_code *c, const ldpc_decode_config *cfg
         if (e != hipSuccess) return fail(LDPC_ERR_HIP, "specialised kernel launch: %s", hipGetErrorString(e));
         if (supported) return LDPC_OK;
     }
-    if (cfg->rule == LDPC_RULE_LNMS)
-        return fail(LDPC_ERR_UNSUPPORTED, "layered min-sum needs a compiled-in circulant code without double-circulant blocks "
-                                          "(and float arithmetic when the posteriors exceed LDS in double)");
+    if (cfg->rule == LDPC_RULE_LNMS) {
+        if (kernel != LDPC_KERNEL_CSR && c->has_qc && !c->qc_pairs) {
+            bool supported = false;
+            hipError_t e = launch_qc_lnms(c->qc, *cfg, compute_dtype, io, c->num_cus, &c->workspace, &c->workspace_bytes,
+                                          &g_kernel, &supported);
+            if (e != hipSuccess) return fail(LDPC_ERR_HIP, "layered kernel launch: %s", hipGetErrorString(e));
+            if (supported) return LDPC_OK;
+        }
+        return fail(LDPC_ERR_UNSUPPORTED, "layered min-sum needs a circulant description without double-circulant blocks, "
+                                          "check degrees up to 24 and posteriors that fit LDS in the chosen arithmetic");
+    }
     if (kernel != LDPC_KERNEL_CSR && c->has_qc && !quirks) {
         bool supported = false;
         hipError_t e = hipSuccess;

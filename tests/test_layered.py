@@ -92,3 +92,52 @@ def test_flooding_rules_on_bg1_through_the_global_workspace(c_oracle):
         res = dec.decode(Lr, cfg, want_posterior=True)
         assert res.kernel.startswith("csr_global")
         assert np.array_equal(res.iters, ei) and np.array_equal(res.hard, eh) and np.array_equal(res.posterior, ep)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["wifi648", "nr_bg2_z40", "nr_bg2_z40_r1400", "nr_bg1_z384"])
+def test_table_driven_layered_kernel_matches_oracle(name, c_oracle):
+    """The layered kernel that reads the base graph from device tables (kernel selector QC), on
+    the packaged codes: same results as the CPU restatement, bit for bit."""
+    from ldpc_amd import _lib
+    from ldpc_amd.decoder import Decoder
+    code = codes.load_packaged(name)
+    dec = Decoder(code)
+    frames = 64 if name == "nr_bg1_z384" else 300
+    L = llrs(code, name, frames, 7)
+    for cfg in (config.LNMS, config.LNMS.with_(early_exit=False, max_iters=4)):
+        eh, ei, ec, ep = c_oracle.c_decode_lnms(code, cfg, L, use_float=True)
+        res = dec.decode(L.astype(np.float32), cfg, compute_dtype=np.float32, want_posterior=True, kernel=2)
+        assert res.kernel in ("qc_lnms_f32", "qc_lnms_global_f32")
+        assert np.array_equal(res.iters, ei) and np.array_equal(res.converged, ec)
+        assert np.array_equal(res.hard, eh) and np.array_equal(res.posterior.astype(np.float64), ep)
+        if name == "nr_bg1_z384":   # 209 KiB of posteriors in double: more than LDS
+            with pytest.raises(_lib.LdpcError) as err:
+                dec.decode(L, cfg, compute_dtype=np.float64, kernel=2)
+            assert err.value.code == _lib.LDPC_ERR_UNSUPPORTED
+            continue
+        eh, ei, ec, ep = c_oracle.c_decode_lnms(code, cfg, L)
+        res = dec.decode(L, cfg, compute_dtype=np.float64, want_posterior=True, kernel=2)
+        assert res.kernel in ("qc_lnms_f64", "qc_lnms_global_f64")
+        assert np.array_equal(res.iters, ei) and np.array_equal(res.converged, ec)
+        assert np.array_equal(res.hard, eh) and np.array_equal(res.posterior, ep)
+
+
+@pytest.mark.gpu
+def test_layered_on_a_base_graph_that_is_not_compiled_in(c_oracle):
+    """A caller's own table: BG1 connectivity with other shift coefficients and a smaller lifting
+    size takes the table-driven layered kernel automatically."""
+    from ldpc_amd import nr_bg1
+    from ldpc_amd.decoder import Decoder
+    for Z, seed in ((384, 5), (96, 6)):
+        code = codes.compile_qc(nr_bg1.build(Z=Z, seed=seed), f"bg1_z{Z}_seed{seed}")
+        dec = Decoder(code)
+        rng = np.random.default_rng([Z, seed])
+        s2 = 1 / (2 * 10 ** (-0.5 / 10))
+        L = ((2 * (1.0 + np.sqrt(s2) * rng.standard_normal((48, code.n)))) / s2).astype(np.float32).astype(np.float64)
+        eh, ei, ec, ep = c_oracle.c_decode_lnms(code, config.LNMS, L, use_float=True)
+        res = dec.decode(L.astype(np.float32), config.LNMS, compute_dtype=np.float32, want_posterior=True)
+        assert res.kernel.startswith("qc_lnms")
+        assert np.array_equal(res.iters, ei) and np.array_equal(res.converged, ec)
+        assert np.array_equal(res.hard, eh) and np.array_equal(res.posterior.astype(np.float64), ep)
+        assert ec.sum() > 0

@@ -7,8 +7,9 @@ sys.path.insert(0, ROOT)
 from ldpc_amd import codes, config, sweep
 from ldpc_amd.decoder import Decoder
 dev = torch.device("cuda", 0)
+KERNEL = 2 if "qc" in sys.argv[1:] else 0   # "qc": the table-driven layered kernel instead of the compiled-in one
 dtypes = [a for a in sys.argv[1:] if a in ("f32", "f64")] or ["f32", "f64"]
-names = [a for a in sys.argv[1:] if a not in ("f32", "f64")] or ["nr_bg1_z384", "nr_bg2_z40", "nr_bg2_z40_r1400", "wifi648"]
+names = [a for a in sys.argv[1:] if a not in ("f32", "f64", "qc")] or ["nr_bg1_z384", "nr_bg2_z40", "nr_bg2_z40_r1400", "wifi648"]
 for name in names:
     code = codes.load_packaged(name); dec = Decoder(code); k = code.n - code.m
     frames = 16384 if code.n > 4096 else 1 << 18
@@ -19,12 +20,12 @@ for name in names:
                                      llr_dtype=torch.float32)
             comp = np.float64 if dtype == "f64" else np.float32
             try:
-                kern = sweep.decode_batch(dec, batch, cfg, compute_dtype=comp)
+                kern = sweep.decode_batch(dec, batch, cfg, compute_dtype=comp, kernel=KERNEL)
             except Exception as e:
                 print(name, dtype, "unsupported", e); break
             torch.cuda.synchronize(); t0 = time.perf_counter()
             for _ in range(3):
-                sweep.decode_batch(dec, batch, cfg, compute_dtype=comp)
+                sweep.decode_batch(dec, batch, cfg, compute_dtype=comp, kernel=KERNEL)
             torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3
             sweep.count_errors(dec, batch); torch.cuda.synchronize()
             st = sweep.summarize(batch.counters.cpu().numpy(), code.n)
