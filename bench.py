@@ -154,11 +154,8 @@ def main():
     from ldpc_amd.decoder import Decoder
 
     code = codes.load_packaged(args.code)
-    if args.code == "nr_bg1_z384":
-        G, k_info = None, code.n - code.m      # all-zero codeword; the dual-diagonal parity part has full rank
-    else:
-        G = codes.load_packaged_generator(args.code)
-        k_info = G.shape[0]
+    G = codes.load_packaged_generator(args.code)   # a k x n matrix, or a structured encoder for BG1
+    k_info = G.k if callable(G) else G.shape[0]
     if args.frames <= 0:
         args.frames = 1 << 20 if code.n <= 1024 else max(1024, (3 << 30) // (4 * code.n) // 1024 * 1024)
     cfg = config.PRESETS[args.rule].with_(max_iters=args.max_iters)
@@ -291,10 +288,11 @@ def other_workloads(code, G, dec, args, torch, dist, device, world, rank):
         run(label, code, G, dec, rule, dtype, snr, early, frames, k)
     # the build-authored NR BG1 Z=384 code under row-layered min-sum (float; see ldpc_amd/nr_bg1.py)
     bg1 = codes.load_packaged("nr_bg1_z384")
+    enc1 = codes.load_packaged_generator("nr_bg1_z384")
     dec1 = Decoder(bg1)
-    run("BG1_Z384_LNMS_f32_fixed_10", bg1, None, dec1, "LNMS", "f32", -3.0, False, 16384, bg1.n - bg1.m)
-    run("BG1_Z384_LNMS_f32_es_n0_-3dB", bg1, None, dec1, "LNMS", "f32", -3.0, True, 16384, bg1.n - bg1.m)
-    run("BG1_Z384_LNMS_f32_es_n0_0dB", bg1, None, dec1, "LNMS", "f32", 0.0, True, 16384, bg1.n - bg1.m)
+    run("BG1_Z384_LNMS_f32_fixed_10", bg1, enc1, dec1, "LNMS", "f32", -3.0, False, 16384, bg1.n - bg1.m)
+    run("BG1_Z384_LNMS_f32_es_n0_-3dB", bg1, enc1, dec1, "LNMS", "f32", -3.0, True, 16384, bg1.n - bg1.m)
+    run("BG1_Z384_LNMS_f32_es_n0_0dB", bg1, enc1, dec1, "LNMS", "f32", 0.0, True, 16384, bg1.n - bg1.m)
     return res
 
 

@@ -358,10 +358,16 @@ def load_packaged(name: str) -> CompiledCode:
     return _cache[name]
 
 
-def load_packaged_generator(name: str) -> np.ndarray:
-    """k x n generator for a packaged code: the one stored with the matrix if the reference's
+def load_packaged_generator(name: str):
+    """k x n generator for a packaged code (for nr_bg1_z384 a callable encoder, see nr_bg1.Encoder): the one stored with the matrix if the reference's
     file carried one (the CCSDS .mat does), else derived by ``gf2_generator``."""
     key = ("G", name)
+    if name == "nr_bg1_z384":
+        # too large for a dense generator: a structured encoder (callable, attribute k) instead
+        if key not in _cache:
+            from . import nr_bg1
+            _cache[key] = nr_bg1.Encoder(nr_bg1.build())
+        return _cache[key]
     if key not in _cache:
         fname, trunc = PACKAGED[name]
         H, G = load_code_npz(os.path.join(_DATA_DIR, fname))

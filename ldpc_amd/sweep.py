@@ -35,7 +35,8 @@ class DeviceBatch:
 def make_batch(code: CompiledCode, G: Optional[np.ndarray], frames: int, snr_db: float,
                cfg: DecodeConfig, seed, device, llr_dtype=None, llr_scale_snr_db: Optional[float] = None
                ) -> DeviceBatch:
-    """Random codewords (all-zero if ``G`` is None), BPSK with the polarity ``cfg`` expects, AWGN
+    """Random codewords (all-zero if ``G`` is None; ``G`` is a k x n generator matrix or a callable
+    encoder with attribute ``k``), BPSK with the polarity ``cfg`` expects, AWGN
     of variance 1/(2*10^(snr/10)) (ldpc.py:245), LLR = 2y/sigma^2 (y/sigma^2 for R2)."""
     import torch
 
@@ -45,6 +46,13 @@ def make_batch(code: CompiledCode, G: Optional[np.ndarray], frames: int, snr_db:
     n = code.n
     if G is None:
         cw = torch.zeros((frames, n), dtype=torch.uint8, device=device)
+    elif callable(G):  # structured encoder (host side), e.g. nr_bg1.Encoder: messages of G.k bits
+        host_rng = np.random.default_rng(np.random.SeedSequence(seed).generate_state(2))
+        cw = torch.empty((frames, n), dtype=torch.uint8, device=device)
+        step = max(1, (1 << 26) // max(n, 1))
+        for a in range(0, frames, step):
+            b = min(frames, a + step)
+            cw[a:b] = torch.as_tensor(G(host_rng.integers(0, 2, size=(b - a, G.k), dtype=np.uint8)), device=device)
     else:
         Gt = torch.as_tensor(np.ascontiguousarray(G), dtype=torch.float32, device=device)
         cw = torch.empty((frames, n), dtype=torch.uint8, device=device)

@@ -31,6 +31,20 @@ def test_bg1_structure():
     assert (deg[26 * 384:] == 1).all()                       # extension parity columns
 
 
+def test_bg1_encoder_makes_codewords():
+    from ldpc_amd import nr_bg1
+    rng = np.random.default_rng(2)
+    for Z, seed in ((384, 38212), (96, 6), (64, 3)):
+        qc = nr_bg1.build(Z=Z, seed=seed)
+        code = codes.compile_qc(qc, "t")
+        info = rng.integers(0, 2, size=(7, 22 * Z), dtype=np.uint8)
+        cw = nr_bg1.encode(qc, info)
+        assert code.is_codeword(cw).all() and np.array_equal(cw[:, :22 * Z], info)
+    enc = codes.load_packaged_generator("nr_bg1_z384")
+    info = rng.integers(0, 2, size=(3, enc.k), dtype=np.uint8)
+    assert enc.k == 8448 and codes.load_packaged("nr_bg1_z384").is_codeword(enc(info)).all()
+
+
 @pytest.mark.parametrize("name", ["wifi648", "nr_bg2_z40"])
 def test_numpy_and_c_layered_oracles_agree(name, c_oracle):
     code = codes.load_packaged(name)
