@@ -313,18 +313,35 @@ lnms_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__r
                     if (post_out) post_out[frame * n + bc * Z + z] = v;
                 }
             });
-            T ring[PFR];
-            static_for<0, (PFR < NPR ? PFR : NPR)>([&](auto j) { ring[j] = load_priv(IC<PL::priv_row(j)>{}); });
-            static_for<0, MB>([&](auto br) {
-                if constexpr (PL::priv_pos(br) >= 0) {
-                    constexpr int j = PL::priv_row_ord(br);
-                    const T v = priv_value(br, ring[j % PFR]);
-                    if constexpr (j + PFR < NPR) ring[j % PFR] = load_priv(IC<PL::priv_row(j + PFR < NPR ? j + PFR : 0)>{});
-                    const int i = priv_index(br);
-                    hard_out[frame * n + i] = (uint8_t)hard_bit<1>(v);
-                    if (post_out) post_out[frame * n + i] = v;
-                }
-            });
+            if (post_out) {  // posteriors wanted: L + r needs the channel LLRs again
+                T ring[PFR];
+                static_for<0, (PFR < NPR ? PFR : NPR)>([&](auto j) { ring[j] = load_priv(IC<PL::priv_row(j)>{}); });
+                static_for<0, MB>([&](auto br) {
+                    if constexpr (PL::priv_pos(br) >= 0) {
+                        constexpr int j = PL::priv_row_ord(br);
+                        const T v = priv_value(br, ring[j % PFR]);
+                        if constexpr (j + PFR < NPR) ring[j % PFR] = load_priv(IC<PL::priv_row(j + PFR < NPR ? j + PFR : 0)>{});
+                        const int i = priv_index(br);
+                        hard_out[frame * n + i] = (uint8_t)hard_bit<1>(v);
+                        post_out[frame * n + i] = v;
+                    }
+                });
+            } else {         // hard decisions only: they sit in bit 30 of the state words
+                static_for<0, MB>([&](auto br) {
+                    if constexpr (PL::priv_pos(br) >= 0) {
+                        unsigned hb;
+                        if constexpr (PL::rdeg(br) >= 2) {
+                            T a, b;
+                            unsigned w;
+                            load_state(br, a, b, w);
+                            hb = (w >> 30) & 1u;
+                        } else {
+                            hb = hard_bit<1>(load_priv(br));
+                        }
+                        hard_out[frame * n + priv_index(br)] = (uint8_t)hb;
+                    }
+                });
+            }
             if (z == 0) { iters_out[frame] = iters; conv_out[frame] = (uint8_t)conv; }
         };
 

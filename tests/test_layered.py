@@ -76,6 +76,9 @@ def test_layered_kernel_matches_oracle(name, c_oracle):
         assert np.array_equal(res.posterior.astype(np.float64), ep)
         if cfg.early_exit:
             assert 0 < ec.sum()
+        # without posteriors the decisions of degree-one variables come from the check state
+        res = dec.decode(L.astype(np.float32), cfg, compute_dtype=np.float32)
+        assert np.array_equal(res.hard, eh) and np.array_equal(res.iters, ei) and np.array_equal(res.converged, ec)
         eh, ei, ec, ep = c_oracle.c_decode_lnms(code, cfg, L)
         res = dec.decode(L, cfg, compute_dtype=np.float64, want_posterior=True)
         assert res.kernel == "spec_lnms_f64"
