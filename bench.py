@@ -277,6 +277,17 @@ def other_workloads(code, G, dec, args, torch, dist, device, world, rank):
 
     frames = min(args.frames, 1 << 19)
     k = G.shape[0]
+    # the step in front of the decoder: BPSK + AWGN + LLRs generated on the device (n bytes in, 4n out)
+    from ldpc_amd import channel
+    cfg0 = config.PRESETS["R0"]
+    probe = sweep.make_batch(code, G, frames, args.snr, cfg0, seed=[9, rank], device=device, native_noise=True)
+    gen = lambda: channel.channel_llr_device(probe.ref.data_ptr(), code.n, frames, code.n, args.snr, cfg0, 7, 0,
+                                             probe.llr.data_ptr(), np.float32,
+                                             stream=torch.cuda.current_stream().cuda_stream)
+    wall, _ = timed_steps(gen, 5, 1, torch, dist, world)
+    res["channel_llr_f32"] = {"gb_s": 5 * code.n * frames * 5 * world / wall / 1e9, "frames": frames, "code": code.name,
+                              "ms_per_launch": wall / 5 * 1e3, "bytes_per_frame": 5 * code.n}
+    del probe
     for label, rule, dtype, snr, early in [
         ("R0_f64_es_n0_1dB", "R0", "f64", 1.0, True),
         ("R0_f32_worst_case", "R0", "f32", args.snr, True),

@@ -39,9 +39,10 @@ extern "C" {
  * posteriors P, forms r_new = scale * min-of-the-others * sign-product-of-the-others and writes
  * P = q + r_new back at once.  A variable that takes part in one check only sends that check its
  * channel LLR itself (its exact extrinsic value).  Iteration count, syndrome test at the top of
- * each iteration, LLR polarity and hard decision are those of R1.  Served for the packaged
- * circulant codes without double-circulant blocks (all checks of a block row then touch distinct
- * variables) and with at most one degree-one variable per check; LDPC_ERR_UNSUPPORTED otherwise.
+ * each iteration, LLR polarity and hard decision are those of R1.  Served for handles with a
+ * circulant description (ldpc_code_attach_qc) without double-circulant blocks (all checks of a
+ * block row then touch distinct variables), check degree <= 24 and posteriors that fit LDS;
+ * LDPC_ERR_UNSUPPORTED otherwise.
  */
 #define LDPC_RULE_LNMS 5
 
@@ -156,6 +157,23 @@ int32_t ldpc_decode_batch_host(ldpc_code *code, const ldpc_decode_config *cfg, c
 int32_t ldpc_count_errors(const uint8_t *hard_dev, const uint8_t *ref_dev, int64_t ref_stride,
                           const int32_t *iters_dev, const uint8_t *converged_dev, int64_t frames,
                           int32_t n, uint64_t *counters_dev, void *stream);
+
+/*
+ * The step in front of the decode path, on the device: BPSK, white Gaussian noise and the channel
+ * LLRs of a batch (addNoiseBPSK, /root/reference/ldpc.py:241-266, and the LLR lines at the top of
+ * the decode methods: ldpc.py:143-151, bpsk.py:159-167,271-277, channel.py:268-274,410-416).
+ *   x = 2b - 1 if plus_is_bit (ldpc.py:257) else 1 - 2b;  y = x + sqrt(sigma2) * N(0,1);
+ *   llr = gain * y, except llr = prefix_llr at positions < prefix_len (bpsk.py:163, channel.py:412).
+ * ref_dev: [frames, n] uint8 code bits (ref_stride = n), one shared codeword (ref_stride = 0) or
+ * NULL for the all-zero codeword.  Noise: Philox4x32-10 keyed by `seed`, counter = (first_frame +
+ * frame index, position / 4), Box-Muller in float: a frame's noise depends on its absolute index
+ * only, so ranks can shard a sweep by frame ranges.  The reference's own noise stream (numpy's
+ * global generator) cannot be reproduced; nothing pins these values but this build's oracle.
+ */
+int32_t ldpc_channel_llr(const uint8_t *ref_dev, int64_t ref_stride, int64_t frames, int32_t n,
+                         double sigma2, double gain, int32_t plus_is_bit, int32_t prefix_len,
+                         double prefix_llr, uint64_t seed, uint64_t first_frame, void *llr_dev,
+                         int32_t llr_dtype, void *stream);
 
 /* name of the kernel variant the last ldpc_decode_batch on this thread launched (for tests) */
 const char *ldpc_last_kernel(void);

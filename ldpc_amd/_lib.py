@@ -19,7 +19,7 @@ KERNEL_AUTO, KERNEL_CSR, KERNEL_QC = 0, 1, 2
 #: every symbol include/ldpc_amd.h declares
 SYMBOLS = ["ldpc_last_error", "ldpc_abi_version", "ldpc_device_count", "ldpc_code_create_csr",
            "ldpc_code_attach_qc", "ldpc_code_destroy", "ldpc_code_info", "ldpc_decode_batch",
-           "ldpc_decode_batch_host", "ldpc_count_errors", "ldpc_last_kernel"]
+           "ldpc_decode_batch_host", "ldpc_count_errors", "ldpc_channel_llr", "ldpc_last_kernel"]
 
 
 class LdpcError(RuntimeError):
@@ -85,6 +85,9 @@ def load() -> ctypes.CDLL:
                                            i64, vp, vp, vp, vp]
     lib.ldpc_count_errors.restype = i32
     lib.ldpc_count_errors.argtypes = [vp, vp, i64, vp, vp, i64, i32, vp, vp]
+    lib.ldpc_channel_llr.restype = i32
+    lib.ldpc_channel_llr.argtypes = [vp, i64, i64, i32, ctypes.c_double, ctypes.c_double, i32, i32,
+                                     ctypes.c_double, ctypes.c_uint64, ctypes.c_uint64, vp, i32, vp]
     _lib = lib
     return lib
 

@@ -26,7 +26,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 #: (object name, source, extra flags)
 UNITS = [("ldpc_abi.o", "ldpc_abi.hip", []),
          ("decode_csr.o", "decode_csr.hip", []),
-         ("count_errors.o", "count_errors.hip", [])]
+         ("count_errors.o", "count_errors.hip", []),
+         ("channel.o", "channel.hip", [])]
 UNITS += [("decode_qc_r0.o", "decode_qc_r0.hip", []), ("decode_spec.o", "decode_spec.hip", []),
           ("decode_lnms.o", "decode_lnms.hip", []),
           ("decode_qc_lnms.o", "decode_qc_lnms.hip", [])]

@@ -53,3 +53,26 @@ def llr_from_samples(y: np.ndarray, snr_db, cfg: DecodeConfig, compat_prefix: bo
         elif cfg.rule in (RULE_R3, RULE_R4):
             L[..., :PUNCTURE_PREFIX] = 0.0
     return L
+
+
+def channel_llr_device(ref_ptr: int, ref_stride: int, frames: int, n: int, snr_db: float, cfg: DecodeConfig,
+                       seed: int, first_frame: int, llr_ptr: int, llr_dtype=np.float32, stream: int = 0,
+                       compat_prefix: bool = False, llr_scale_snr_db=None) -> None:
+    """The same on the device, for a whole batch (``ldpc_channel_llr``): BPSK with the polarity
+    ``cfg`` assumes, noise of variance ``noise_variance(snr_db)``, LLR gain 2/sigma^2 (1/sigma^2 for
+    R2) taken at ``llr_scale_snr_db`` if the receiver's SNR estimate differs from the channel's, and
+    the rule's overwritten prefix when ``compat_prefix``.  ``ref_ptr`` = 0 sends the all-zero
+    codeword.  Frame f of the call gets the noise of absolute frame ``first_frame + f``."""
+    from . import _lib
+    sigma2 = float(noise_variance(snr_db))
+    sigma2_llr = sigma2 if llr_scale_snr_db is None else float(noise_variance(llr_scale_snr_db))
+    gain = (1.0 if cfg.rule == RULE_R2 else 2.0) / sigma2_llr
+    plen, pval = 0, 0.0
+    if compat_prefix and cfg.rule == RULE_R1:
+        plen, pval = PUNCTURE_PREFIX, 1e-9
+    elif compat_prefix and cfg.rule in (RULE_R3, RULE_R4):
+        plen, pval = PUNCTURE_PREFIX, 0.0
+    _lib.check(_lib.load().ldpc_channel_llr(ref_ptr or None, int(ref_stride), int(frames), int(n), sigma2, gain,
+                                            int(cfg.plus_is_bit == 1), plen, pval, int(seed) & (2 ** 64 - 1),
+                                            int(first_frame), llr_ptr, 1 if np.dtype(llr_dtype) == np.float64 else 0,
+                                            stream or None))

@@ -81,5 +81,10 @@ hipError_t launch_qc_lnms(const QcDev &code, const ldpc_decode_config &cfg, int 
 hipError_t launch_count_errors(const uint8_t *hard, const uint8_t *ref, long long ref_stride,
                                const int *iters, const uint8_t *conv, long long frames, int n,
                                unsigned long long *counters, hipStream_t stream);
+// channel.hip
+hipError_t launch_channel_llr(const uint8_t *ref, long long ref_stride, long long frames, int n, double sigma2,
+                              double gain, int plus_is_bit, int prefix_len, double prefix_llr,
+                              unsigned long long seed, unsigned long long first_frame, void *llr, int llr_dtype,
+                              hipStream_t stream);
 
 }  // namespace ldpc

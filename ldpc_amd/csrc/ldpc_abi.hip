@@ -363,3 +363,21 @@ extern "C" int32_t ldpc_count_errors(const uint8_t *hard_dev, const uint8_t *ref
     if (e != hipSuccess) return fail(LDPC_ERR_HIP, "count_errors launch: %s", hipGetErrorString(e));
     return LDPC_OK;
 }
+
+extern "C" int32_t ldpc_channel_llr(const uint8_t *ref_dev, int64_t ref_stride, int64_t frames, int32_t n,
+                                    double sigma2, double gain, int32_t plus_is_bit, int32_t prefix_len,
+                                    double prefix_llr, uint64_t seed, uint64_t first_frame, void *llr_dev,
+                                    int32_t llr_dtype, void *stream)
+{
+    if (frames < 0 || n <= 0) return fail(LDPC_ERR_ARG, "bad frame count or n");
+    if (frames == 0) return LDPC_OK;
+    if (!llr_dev) return fail(LDPC_ERR_ARG, "NULL buffer");
+    if (llr_dtype != LDPC_F32 && llr_dtype != LDPC_F64) return fail(LDPC_ERR_ARG, "dtype must be LDPC_F32 or LDPC_F64");
+    if (ref_dev && ref_stride != 0 && ref_stride != n) return fail(LDPC_ERR_ARG, "ref_stride must be 0 or n");
+    if (!(sigma2 >= 0.0) || prefix_len < 0) return fail(LDPC_ERR_ARG, "negative noise variance or prefix length");
+    hipError_t e = launch_channel_llr(ref_dev, ref_stride, frames, n, sigma2, gain, plus_is_bit != 0, prefix_len,
+                                      prefix_llr, seed, first_frame, llr_dev, llr_dtype,
+                                      reinterpret_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(LDPC_ERR_HIP, "channel_llr launch: %s", hipGetErrorString(e));
+    return LDPC_OK;
+}

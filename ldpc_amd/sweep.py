@@ -33,8 +33,8 @@ class DeviceBatch:
 
 
 def make_batch(code: CompiledCode, G: Optional[np.ndarray], frames: int, snr_db: float,
-               cfg: DecodeConfig, seed, device, llr_dtype=None, llr_scale_snr_db: Optional[float] = None
-               ) -> DeviceBatch:
+               cfg: DecodeConfig, seed, device, llr_dtype=None, llr_scale_snr_db: Optional[float] = None,
+               native_noise: bool = False, first_frame: int = 0) -> DeviceBatch:
     """Random codewords (all-zero if ``G`` is None; ``G`` is a k x n generator matrix or a callable
     encoder with attribute ``k``), BPSK with the polarity ``cfg`` expects, AWGN
     of variance 1/(2*10^(snr/10)) (ldpc.py:245), LLR = 2y/sigma^2 (y/sigma^2 for R2)."""
@@ -61,6 +61,21 @@ def make_batch(code: CompiledCode, G: Optional[np.ndarray], frames: int, snr_db:
             b = min(frames, a + step)
             msg = torch.randint(0, 2, (b - a, Gt.shape[0]), generator=gen, device=device, dtype=torch.int32)
             cw[a:b] = torch.remainder(msg.to(torch.float32) @ Gt, 2.0).to(torch.uint8)
+    if native_noise:
+        # noise and LLRs from the library's own kernel: frame f gets the noise of absolute frame
+        # first_frame + f, whatever batch or rank it is generated in
+        from . import channel
+        llr = torch.empty((frames, n), dtype=llr_dtype, device=device)
+        key = int(np.random.SeedSequence(seed).generate_state(1, dtype=np.uint64)[0])
+        channel.channel_llr_device(cw.data_ptr(), n, frames, n, snr_db, cfg, key, first_frame, llr.data_ptr(),
+                                   np.float32 if llr_dtype == torch.float32 else np.float64,
+                                   stream=torch.cuda.current_stream().cuda_stream,
+                                   llr_scale_snr_db=llr_scale_snr_db)
+        return DeviceBatch(llr, cw,
+                           torch.empty((frames, n), dtype=torch.uint8, device=device),
+                           torch.empty((frames,), dtype=torch.int32, device=device),
+                           torch.empty((frames,), dtype=torch.uint8, device=device),
+                           torch.zeros((5,), dtype=torch.int64, device=device))
     sigma2 = 1.0 / (2.0 * 10.0 ** (snr_db / 10.0))
     sigma2_llr = sigma2 if llr_scale_snr_db is None else 1.0 / (2.0 * 10.0 ** (llr_scale_snr_db / 10.0))
     gain = (1.0 if cfg.rule == 2 else 2.0) / sigma2_llr
