@@ -39,11 +39,11 @@ __device__ __forceinline__ void box_muller(unsigned a, unsigned b, float &n0, fl
 {
     const float u1 = ((float)a + 0.5f) * 2.3283064365386963e-10f;  // 2^-32; never 0, may round to 1
     const float u2 = ((float)b + 0.5f) * 2.3283064365386963e-10f;
-    const float r = sqrtf(-2.0f * logf(u1 < 1.0f ? u1 : 0.99999994f));
-    float s, c;
-    sincosf(6.283185307179586f * u2, &s, &c);
-    n0 = r * c;
-    n1 = r * s;
+    // hardware log2 / sin / cos (the latter take their argument in turns): a few 1e-7 absolute,
+    // far below the quantisation of the uniforms themselves
+    const float r = __builtin_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1 < 1.0f ? u1 : 0.99999994f));
+    n0 = r * __builtin_amdgcn_cosf(u2);
+    n1 = r * __builtin_amdgcn_sinf(u2);
 }
 
 template <typename TL>
