@@ -73,6 +73,9 @@ hipError_t launch_spec(int spec_id, const ldpc_decode_config &cfg, int compute_d
 // decode_lnms.hip: row-layered min-sum, specialised for the packaged codes (same spec_id)
 hipError_t launch_spec_lnms(int spec_id, const ldpc_decode_config &cfg, int compute_dtype, const Launch &io,
                             int num_cus, const char **kernel_name, bool *supported);
+// decode_spec_spa.hip: sum-product rules R2-R4, specialised for the small packaged codes
+hipError_t launch_spec_spa(int spec_id, const ldpc_decode_config &cfg, int compute_dtype, const Launch &io,
+                           int num_cus, const char **kernel_name, bool *supported);
 // decode_qc_lnms.hip: the same rule for any circulant code, base graph in device tables
 hipError_t launch_qc_lnms(const QcDev &code, const ldpc_decode_config &cfg, int compute_dtype, const Launch &io,
                           int num_cus, void **workspace, size_t *workspace_bytes, const char **kernel_name,

@@ -214,27 +214,6 @@ spec_r0_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *
 // Hard decisions (`0 if b > 0 else 1`, bpsk.py:240-243) never touch memory: a ballot per block
 // column gives a 64-bit mask in scalar registers, and the syndrome of block row br is the XOR of
 // those masks rotated by the circulant shifts — a handful of scalar instructions per base edge.
-template <int Z, int F>
-constexpr unsigned long long replicate_field(unsigned long long x)
-{
-    unsigned long long r = 0;
-    for (int f = 0; f < F; ++f) r |= x << (f * Z);
-    return r;
-}
-// bit (f*Z + z) of the result = bit (f*Z + (z + S) mod Z) of m, for every slot f
-template <int Z, int F, int S>
-__device__ __forceinline__ unsigned long long rot_fields(unsigned long long m)
-{
-    if constexpr (S == 0) return m;
-    else if constexpr (Z == 64) return (m >> S) | (m << (64 - S));
-    else {
-        constexpr unsigned long long field = (1ull << Z) - 1ull;
-        constexpr unsigned long long low = replicate_field<Z, F>(field >> S);
-        constexpr unsigned long long high = replicate_field<Z, F>(field & ~(field >> S));
-        return ((m >> S) & low) | ((m << (Z - S)) & high);
-    }
-}
-
 template <class C, typename T, int F>
 struct R1Layout {
     static constexpr int THREADS = ((F * C::Z + 63) / 64) * 64;
@@ -244,21 +223,6 @@ struct R1Layout {
     static constexpr int LDS_BYTES = F * SLOT_BYTES;
     static constexpr bool QREG = C::EB * (int)sizeof(T) / 4 <= 72;  // own messages in registers
 };
-
-template <class C, int F>
-__device__ __forceinline__ bool r1_slot_ok(const unsigned long long (&hm)[C::NB], unsigned long long slot_mask)
-{
-    unsigned long long bad = 0ull;
-    static_for<0, C::MB>([&](auto br) {
-        constexpr int e0 = C::row_ptr[br], D = C::row_ptr[br + 1] - e0;
-        unsigned long long acc = 0ull;
-        static_for<0, D>([&](auto p) {
-            acc ^= rot_fields<C::Z, F, C::row_shift[e0 + p]>(hm[C::row_col[e0 + p]]);
-        });
-        bad |= acc;
-    });
-    return (bad & slot_mask) == 0ull;
-}
 
 template <class C, typename T, typename TL, int F>
 __global__ void __launch_bounds__(64) LDPC_SPEC_OCC
@@ -493,6 +457,8 @@ hipError_t launch_spec(int spec_id, const ldpc_decode_config &cfg, int compute_d
 {
     if (cfg.rule == LDPC_RULE_LNMS)  // decode_lnms.hip
         return launch_spec_lnms(spec_id, cfg, compute_dtype, io, num_cus, name, supported);
+    if (cfg.rule >= 2 && cfg.rule <= 4)  // decode_spec_spa.hip
+        return launch_spec_spa(spec_id, cfg, compute_dtype, io, num_cus, name, supported);
     int id = 0;
 #define LDPC_LAUNCH(CODE, SLOTS)                                                                   \
     if (spec_id == id) return launch_spec_code<CODE, SLOTS>(cfg, compute_dtype, io, num_cus, name, supported); \

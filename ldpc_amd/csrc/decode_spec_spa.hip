@@ -1,0 +1,240 @@
+// Code-specialised sum-product decoders (rules R2, R3, R4) for the small packaged codes.
+//
+// Same construction as the specialised min-sum kernels (decode_spec.hip): the base graph is a
+// template parameter, one wave is one workgroup (F frames side by side when Z < 64), no barriers.
+//   msg [EB][Z]  one message per edge, in check order (by-row edge index, check's z), updated in
+//                place: check (br, z) reads its variable-to-check messages at [e][z] and overwrites
+//                them with its check-to-variable messages; variable (bc, z') finds edge k of its
+//                column at [col_slot[k]][(z' - shift) mod Z] and writes the next variable-to-check
+//                message there.  LDS operations of one wave execute in order, which is all the
+//                synchronisation this needs.
+// Channel LLRs and posteriors live in registers; hard decisions are ballots and the syndrome is
+// scalar code (see r1_slot_ok).
+//
+// R2  bpsk.py:263-387     tanh rule, inner clip 20, product clip 0.999999999, posterior clip 30
+// R3  channel.py:402-513  tanh rule, 0.85 * 2 * atanh, product clip 0.99999999, posterior clip 50
+// R4  channel.py:260-398  phi rule, sum clip [1e-12, 20], posterior clip 500
+// The clips arrive in the configuration; prefix products and suffix products replace the
+// reference's per-target loops (agreement to rounding, see the table-driven kernel).
+#include "spec_common.h"
+
+namespace ldpc {
+
+template <class C, typename T, int F>
+struct SpaLayout {
+    static constexpr int THREADS = ((F * C::Z + 63) / 64) * 64;
+    static constexpr int MSG_BYTES = C::EB * C::Z * (int)sizeof(T);
+    static constexpr int SLOT_BYTES = ((MSG_BYTES + 127) / 128) * 128 + (F > 1 ? 32 : 0);
+    static constexpr int LDS_BYTES = F * SLOT_BYTES;
+};
+
+template <int RULE, class C, typename T, typename TL, int F>
+__global__ void __launch_bounds__(64)
+spec_spa_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__restrict__ hard_out,
+                int *__restrict__ iters_out, uint8_t *__restrict__ conv_out, T *__restrict__ post_out)
+{
+    typedef SpaLayout<C, T, F> LY;
+    static_assert(LY::THREADS == 64, "single-wave workgroups only");
+    constexpr int Z = C::Z, NB = C::NB, MB = C::MB, ST = sizeof(T);
+    constexpr int n = NB * Z;
+    extern __shared__ __align__(16) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const bool lane_on = tid < F * Z;
+    const int f = lane_on ? tid / Z : 0;
+    const int z = lane_on ? tid - f * Z : 0;
+    unsigned char *msg_b = smem + f * LY::SLOT_BYTES;  // [EB][Z] T
+    const unsigned zb = (unsigned)z * ST;
+    const unsigned long long slot_mask = (Z >= 64 ? ~0ull : ((1ull << (Z & 63)) - 1ull)) << ((f * Z) & 63);
+
+    const long long groups = (frames + F - 1) / F;
+    for (long long grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+        const long long frame = grp * F + f;
+        const bool active = lane_on && frame < frames;
+        T L[NB], own[NB];
+        unsigned long long hm[NB];
+        static_for<0, NB>([&](auto bc) {
+            constexpr int k0 = C::col_ptr[bc], D = C::col_ptr[bc + 1] - k0;
+            const T l = active ? (T)llr[frame * n + bc * Z + z] : (T)0;
+            L[bc] = l;
+            own[bc] = l;
+            hm[bc] = __ballot(!(l > (T)0));
+            static_for<0, D>([&](auto k) {  // bpsk.py:299-306: every edge starts with the channel LLR
+                constexpr int e = C::col_slot[k0 + k], s = C::col_shift[k0 + k];
+                if (lane_on) *reinterpret_cast<T *>(msg_b + e * Z * ST + rot_bwd<Z, ST, s>(zb)) = l;  // idle lanes alias lane 0
+            });
+        });
+
+        auto write_out = [&](int iters, int conv) {
+            static_for<0, NB>([&](auto bc) {
+                hard_out[frame * n + bc * Z + z] = (uint8_t)hard_bit<RULE>(own[bc]);
+                if (post_out) post_out[frame * n + bc * Z + z] = own[bc];
+            });
+            if (z == 0) { iters_out[frame] = iters; conv_out[frame] = (uint8_t)conv; }
+        };
+
+        bool done = !active;
+        for (int t = 0; t < g.max_iters; ++t) {
+            if (g.early_exit) {  // bpsk.py:311-316
+                const bool ok = r1_slot_ok<C, F>(hm, slot_mask);
+                if (!done && ok) { write_out(t, 1); done = true; }
+                if (__ballot(!done) == 0ull) break;
+            }
+            if (!done) {
+                // ---- check nodes
+                static_for<0, MB>([&](auto br) {
+                    constexpr int e0 = C::row_ptr[br], D = C::row_ptr[br + 1] - e0;
+                    T v[D > 0 ? D : 1];
+                    static_for<0, D>([&](auto p) { v[p] = *reinterpret_cast<const T *>(msg_b + (e0 + p) * Z * ST + zb); });
+                    if constexpr (RULE == 2 || RULE == 3) {  // bpsk.py:325-339, channel.py:471-474
+                        T th[D > 0 ? D : 1], suf[D > 0 ? D : 1];
+                        static_for<0, D>([&](auto p) { th[p] = spa_tanh_half(v[p], g.clip_tanh_arg); });
+                        T run = (T)1;
+                        static_for<0, D>([&](auto pp) { constexpr int p = D - 1 - pp; suf[p] = run; run *= th[p]; });
+                        T pre = (T)1;
+                        static_for<0, D>([&](auto p) {
+                            *reinterpret_cast<T *>(msg_b + (e0 + p) * Z * ST + zb) =
+                                spa_message(pre * suf[p], g.clip_prod, g.scale, RULE == 3);
+                            pre *= th[p];
+                        });
+                    } else {  // channel.py:332-352
+                        T ph[D > 0 ? D : 1], suf[D > 0 ? D : 1];
+                        unsigned neg = 0;
+                        static_for<0, D>([&](auto p) {
+                            neg |= (unsigned)(v[p] < (T)0) << p;  // 0 and 1e-9 count as +
+                            ph[p] = phi(t_abs(v[p]));
+                        });
+                        T run = (T)0;
+                        static_for<0, D>([&](auto pp) { constexpr int p = D - 1 - pp; suf[p] = run; run += ph[p]; });
+                        T pre = (T)0;
+                        static_for<0, D>([&](auto p) {
+                            const bool negative = (__popc(neg & ~(1u << p)) & 1) != 0;
+                            *reinterpret_cast<T *>(msg_b + (e0 + p) * Z * ST + zb) = phi_message(pre + suf[p], negative);
+                            pre += ph[p];
+                        });
+                    }
+                });
+                // ---- variable nodes (bpsk.py:346-375, channel.py:358-367, 480-491)
+                static_for<0, NB>([&](auto bc) {
+                    constexpr int k0 = C::col_ptr[bc], D = C::col_ptr[bc + 1] - k0;
+                    T r[D > 0 ? D : 1], qn[D > 0 ? D : 1];
+                    unsigned off[D > 0 ? D : 1];
+                    static_for<0, D>([&](auto k) {
+                        constexpr int e = C::col_slot[k0 + k], s = C::col_shift[k0 + k];
+                        off[k] = e * Z * ST + rot_bwd<Z, ST, s>(zb);
+                        r[k] = *reinterpret_cast<const T *>(msg_b + off[k]);
+                    });
+                    bool sw[D > 0 ? D : 1];
+                    static_for<0, (D > 0 ? D - 1 : 0)>([&](auto k) {
+                        if constexpr (C::col_pair[k0 + k] != 0) {  // two circulants in one block: lower check index first
+                            constexpr int s0 = C::col_shift[k0 + k], s1 = C::col_shift[k0 + k + 1];
+                            sw[k] = rot_bwd<Z, ST, s0>(zb) > rot_bwd<Z, ST, s1>(zb);
+                            const T a = r[k], b = r[k + 1];
+                            r[k] = sw[k] ? b : a;
+                            r[k + 1] = sw[k] ? a : b;
+                        }
+                    });
+                    T run = (T)0;
+                    static_for<0, D>([&](auto k) {
+                        T ext = run;
+                        static_for<k + 1, D>([&](auto kk) { ext += r[kk]; });
+                        run += r[k];
+                        qn[k] = L[bc] + ext;
+                    });
+                    static_for<0, (D > 0 ? D - 1 : 0)>([&](auto k) {
+                        if constexpr (C::col_pair[k0 + k] != 0) {
+                            const T a = qn[k], b = qn[k + 1];
+                            qn[k] = sw[k] ? b : a;
+                            qn[k + 1] = sw[k] ? a : b;
+                        }
+                    });
+                    static_for<0, D>([&](auto k) { *reinterpret_cast<T *>(msg_b + off[k]) = qn[k]; });
+                    T b = L[bc] + run;
+                    if (g.clip_post > (T)0) b = clip(b, -g.clip_post, g.clip_post);
+                    own[bc] = b;
+                    hm[bc] = __ballot(!(b > (T)0));
+                });
+            }
+        }
+        if (!done) {
+            if (g.early_exit) write_out(g.max_iters - 1, 0);
+            else write_out(g.max_iters, r1_slot_ok<C, F>(hm, slot_mask) ? 1 : 0);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ host
+// One wave per workgroup: with fewer than eight resident workgroups per compute unit (LDS or
+// registers) the long dependent chains of the transcendentals are not hidden and the table-driven
+// kernel, which spreads a frame over several waves, is faster; *supported = false sends the call there.
+template <int RULE, class C, typename T, typename TL, int F>
+static hipError_t launch_spa(const ldpc_decode_config &cfg, const Launch &io, int num_cus, const char **name,
+                             bool *supported)
+{
+    typedef SpaLayout<C, T, F> LY;
+    Cfg<T> g;
+    g.rule = RULE; g.max_iters = cfg.max_iters; g.early_exit = cfg.early_exit;
+    g.float_syndrome0 = 0; g.num_active_checks = -1; g.num_refresh_vars = -1;
+    g.scale = (T)cfg.scale; g.clip_tanh_arg = (T)cfg.clip_tanh_arg; g.clip_prod = (T)cfg.clip_prod;
+    g.clip_post = (T)cfg.clip_post;
+    auto k = spec_spa_kernel<RULE, C, T, TL, F>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LY::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    int per_cu = 0;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k), 64, LY::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    if (per_cu < 8) { *supported = false; return hipSuccess; }
+    const long long groups = (io.frames + F - 1) / F;
+    long long grid = (long long)num_cus * per_cu * 2;
+    if (grid > groups) grid = groups;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(64), LY::LDS_BYTES, io.stream, g,
+                       reinterpret_cast<const TL *>(io.llr), io.frames, io.hard, io.iters, io.converged,
+                       reinterpret_cast<T *>(io.posterior));
+    *name = sizeof(T) == 8 ? "spec_spa_f64" : "spec_spa_f32";
+    return hipGetLastError();
+}
+
+template <int RULE, class C, int F>
+static hipError_t launch_spa_rule(const ldpc_decode_config &cfg, int compute_dtype, const Launch &io, int num_cus,
+                                  const char **name, bool *supported)
+{
+    *supported = true;
+    if (compute_dtype == LDPC_F64) {
+        if (io.llr_dtype == LDPC_F64) return launch_spa<RULE, C, double, double, F>(cfg, io, num_cus, name, supported);
+        return launch_spa<RULE, C, double, float, F>(cfg, io, num_cus, name, supported);
+    }
+    if (io.llr_dtype == LDPC_F32) return launch_spa<RULE, C, float, float, F>(cfg, io, num_cus, name, supported);
+    *supported = false;
+    return hipSuccess;
+}
+
+template <class C, int F>
+static hipError_t launch_spa_code(const ldpc_decode_config &cfg, int compute_dtype, const Launch &io, int num_cus,
+                                  const char **name, bool *supported)
+{
+    *supported = false;
+    // small base graphs only: the whole graph is unrolled
+    if constexpr (C::EB <= 100 && SpaLayout<C, double, F>::THREADS == 64 && SpaLayout<C, double, F>::LDS_BYTES <= 160 * 1024) {
+        if (cfg.rule == 2) return launch_spa_rule<2, C, F>(cfg, compute_dtype, io, num_cus, name, supported);
+        if (cfg.rule == 3) return launch_spa_rule<3, C, F>(cfg, compute_dtype, io, num_cus, name, supported);
+        if (cfg.rule == 4) return launch_spa_rule<4, C, F>(cfg, compute_dtype, io, num_cus, name, supported);
+    }
+    return hipSuccess;
+}
+
+hipError_t launch_spec_spa(int spec_id, const ldpc_decode_config &cfg, int compute_dtype, const Launch &io,
+                           int num_cus, const char **name, bool *supported)
+{
+    int id = 0;
+#define LDPC_LAUNCH(CODE, SLOTS)                                                                   \
+    if (spec_id == id) return launch_spa_code<CODE, SLOTS>(cfg, compute_dtype, io, num_cus, name, supported); \
+    ++id;
+    LDPC_FOR_EACH_SPEC_CODE(LDPC_LAUNCH)
+#undef LDPC_LAUNCH
+    *supported = false;
+    return hipSuccess;
+}
+
+}  // namespace ldpc

@@ -89,4 +89,43 @@ __device__ __forceinline__ unsigned rot_bwd(unsigned zb)
     return rot_fwd<Z, ELEM, (Z - S) % Z>(zb);
 }
 
+// Hard decisions as ballots: one 64-bit lane mask per block column; the syndrome of a block row is
+// the XOR of those masks rotated by the circulant shifts (scalar instructions only).
+template <int Z, int F>
+constexpr unsigned long long replicate_field(unsigned long long x)
+{
+    unsigned long long r = 0;
+    for (int f = 0; f < F; ++f) r |= x << (f * Z);
+    return r;
+}
+// bit (f*Z + z) of the result = bit (f*Z + (z + S) mod Z) of m, for every slot f
+template <int Z, int F, int S>
+__device__ __forceinline__ unsigned long long rot_fields(unsigned long long m)
+{
+    if constexpr (S == 0) return m;
+    else if constexpr (Z == 64) return (m >> S) | (m << (64 - S));
+    else {
+        constexpr unsigned long long field = (1ull << Z) - 1ull;
+        constexpr unsigned long long low = replicate_field<Z, F>(field >> S);
+        constexpr unsigned long long high = replicate_field<Z, F>(field & ~(field >> S));
+        return ((m >> S) & low) | ((m << (Z - S)) & high);
+    }
+}
+
+template <class C, int F>
+__device__ __forceinline__ bool r1_slot_ok(const unsigned long long (&hm)[C::NB], unsigned long long slot_mask)
+{
+    unsigned long long bad = 0ull;
+    static_for<0, C::MB>([&](auto br) {
+        constexpr int e0 = C::row_ptr[br], D = C::row_ptr[br + 1] - e0;
+        unsigned long long acc = 0ull;
+        static_for<0, D>([&](auto p) {
+            acc ^= rot_fields<C::Z, F, C::row_shift[e0 + p]>(hm[C::row_col[e0 + p]]);
+        });
+        bad |= acc;
+    });
+    return (bad & slot_mask) == 0ull;
+}
+
+
 }  // namespace ldpc
