@@ -99,18 +99,31 @@ spec_r0_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *
         slot_mask = (Z >= 64 ? ~0ull : ((1ull << Z) - 1ull)) << ((f * Z) & 63);
     }
 
+    constexpr bool PREFETCH = LY::SINGLE && llr_prefetch_pays<C, TL>(LY::LDS_BYTES);  // see llr_prefetch
+    __shared__ float stage[PREFETCH ? NB * 64 : 1];           // [NB][lane]
+    auto prefetch = [&](long long g2) {
+        if constexpr (PREFETCH) llr_prefetch<C, F>(stage, llr, g2, frames, lane_on, f, z);
+    };
     const long long groups = (frames + F - 1) / F;
+    if (blockIdx.x < groups) prefetch(blockIdx.x);
     for (long long grp = blockIdx.x; grp < groups; grp += gridDim.x) {
         const long long frame = grp * F + f;
         const bool active = lane_on && frame < frames;
         T L[NB], own[NB];
+        if constexpr (PREFETCH) __builtin_amdgcn_s_waitcnt(0);  // the staged LLRs have landed
         static_for<0, NB>([&](auto bc) {
             // + 0.0 turns -0.0 into +0.0: from here on "negative" is exactly "sign bit set"
-            const T l = (active ? (T)llr[frame * n + bc * Z + z] : (T)0) + (T)0;
+            T l;
+            if constexpr (PREFETCH) l = (active ? (T)stage[bc * 64 + tid] : (T)0) + (T)0;
+            else l = (active ? (T)llr[frame * n + bc * Z + z] : (T)0) + (T)0;
             L[bc] = l;
             own[bc] = l;  // ldpc.py:154
             if (lane_on) *reinterpret_cast<T *>(post_b + bc * Z * ST + zb) = l;  // idle lanes alias lane 0
         });
+        if constexpr (PREFETCH) {
+            __builtin_amdgcn_s_waitcnt(0);  // staging area read out before it is refilled
+            if (grp + gridDim.x < groups) prefetch(grp + gridDim.x);
+        }
         if constexpr (!LY::SINGLE) {
             if (tid < F) slot_bad[tid] = 0;
             __syncthreads();
@@ -245,16 +258,24 @@ spec_r1_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *
     const unsigned zb = (unsigned)z * ST, zp = (unsigned)z * SP;
     const unsigned long long slot_mask = (Z >= 64 ? ~0ull : ((1ull << (Z & 63)) - 1ull)) << ((f * Z) & 63);
 
+    constexpr bool PREFETCH = llr_prefetch_pays<C, TL>(LY::LDS_BYTES);  // see llr_prefetch
+    __shared__ float stage[PREFETCH ? NB * 64 : 1];  // [NB][lane]
     const long long groups = (frames + F - 1) / F;
+    if constexpr (PREFETCH) {
+        if (blockIdx.x < groups) llr_prefetch<C, F>(stage, llr, blockIdx.x, frames, lane_on, f, z);
+    }
     for (long long grp = blockIdx.x; grp < groups; grp += gridDim.x) {
         const long long frame = grp * F + f;
         const bool active = lane_on && frame < frames;
         T L[NB], own[NB];
         T q[LY::QREG ? EB : 1];
         unsigned long long hm[NB];
+        if constexpr (PREFETCH) __builtin_amdgcn_s_waitcnt(0);  // the staged LLRs have landed
         static_for<0, NB>([&](auto bc) {
             constexpr int k0 = C::col_ptr[bc], D = C::col_ptr[bc + 1] - k0;
-            const T l = active ? (T)llr[frame * n + bc * Z + z] : (T)0;
+            T l;
+            if constexpr (PREFETCH) l = active ? (T)stage[bc * 64 + tid] : (T)0;
+            else l = active ? (T)llr[frame * n + bc * Z + z] : (T)0;
             L[bc] = l;
             own[bc] = l;
             hm[bc] = __ballot(!(l > (T)0));
@@ -263,6 +284,10 @@ spec_r1_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *
                 if (lane_on) *reinterpret_cast<T *>(qv_b + (k0 + k) * Z * ST + zb) = l;  // idle lanes alias lane 0
             });
         });
+        if constexpr (PREFETCH) {
+            __builtin_amdgcn_s_waitcnt(0);  // staging area read out before it is refilled
+            if (grp + gridDim.x < groups) llr_prefetch<C, F>(stage, llr, grp + gridDim.x, frames, lane_on, f, z);
+        }
 
         auto write_out = [&](int iters, int conv) {
             static_for<0, NB>([&](auto bc) {
@@ -371,17 +396,18 @@ static hipError_t launch_spec_r0(const ldpc_decode_config &cfg, const Launch &io
     g.rule = 0; g.max_iters = cfg.max_iters; g.early_exit = cfg.early_exit;
     g.float_syndrome0 = cfg.float_syndrome0; g.num_active_checks = -1; g.num_refresh_vars = -1;
     g.scale = (T)cfg.scale; g.clip_tanh_arg = (T)0; g.clip_prod = (T)0; g.clip_post = (T)0;
-    size_t per_cu = (160 * 1024) / LY::LDS_BYTES;
-    const size_t wave_cap = 32 / (LY::THREADS / 64);
-    if (per_cu > wave_cap) per_cu = wave_cap;
-    const long long groups = (io.frames + F - 1) / F;
-    long long grid = (long long)num_cus * (long long)per_cu * 2;
-    if (grid > groups) grid = groups;
-    if (grid < 1) grid = 1;
     auto k = spec_r0_kernel<C, T, TL, F>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LY::LDS_BYTES);
     if (e != hipSuccess) return e;
+    int per_cu = 0;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k), LY::THREADS, LY::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    if (per_cu < 1) per_cu = 1;
+    const long long groups = (io.frames + F - 1) / F;
+    long long grid = (long long)num_cus * (long long)per_cu * 2;
+    if (grid > groups) grid = groups;
+    if (grid < 1) grid = 1;
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(LY::THREADS), LY::LDS_BYTES, io.stream, g,
                        reinterpret_cast<const TL *>(io.llr), io.frames, io.hard, io.iters, io.converged,
                        reinterpret_cast<T *>(io.posterior));

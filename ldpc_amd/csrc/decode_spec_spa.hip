@@ -47,15 +47,23 @@ spec_spa_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t 
     const unsigned zb = (unsigned)z * ST;
     const unsigned long long slot_mask = (Z >= 64 ? ~0ull : ((1ull << (Z & 63)) - 1ull)) << ((f * Z) & 63);
 
+    constexpr bool PREFETCH = llr_prefetch_pays<C, TL>(LY::LDS_BYTES);  // see llr_prefetch
+    __shared__ float stage[PREFETCH ? NB * 64 : 1];  // [NB][lane]
     const long long groups = (frames + F - 1) / F;
+    if constexpr (PREFETCH) {
+        if (blockIdx.x < groups) llr_prefetch<C, F>(stage, llr, blockIdx.x, frames, lane_on, f, z);
+    }
     for (long long grp = blockIdx.x; grp < groups; grp += gridDim.x) {
         const long long frame = grp * F + f;
         const bool active = lane_on && frame < frames;
         T L[NB], own[NB];
         unsigned long long hm[NB];
+        if constexpr (PREFETCH) __builtin_amdgcn_s_waitcnt(0);  // the staged LLRs have landed
         static_for<0, NB>([&](auto bc) {
             constexpr int k0 = C::col_ptr[bc], D = C::col_ptr[bc + 1] - k0;
-            const T l = active ? (T)llr[frame * n + bc * Z + z] : (T)0;
+            T l;
+            if constexpr (PREFETCH) l = active ? (T)stage[bc * 64 + tid] : (T)0;
+            else l = active ? (T)llr[frame * n + bc * Z + z] : (T)0;
             L[bc] = l;
             own[bc] = l;
             hm[bc] = __ballot(!(l > (T)0));
@@ -64,6 +72,10 @@ spec_spa_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t 
                 if (lane_on) *reinterpret_cast<T *>(msg_b + e * Z * ST + rot_bwd<Z, ST, s>(zb)) = l;  // idle lanes alias lane 0
             });
         });
+        if constexpr (PREFETCH) {
+            __builtin_amdgcn_s_waitcnt(0);  // staging area read out before it is refilled
+            if (grp + gridDim.x < groups) llr_prefetch<C, F>(stage, llr, grp + gridDim.x, frames, lane_on, f, z);
+        }
 
         auto write_out = [&](int iters, int conv) {
             static_for<0, NB>([&](auto bc) {

@@ -89,6 +89,37 @@ __device__ __forceinline__ unsigned rot_bwd(unsigned zb)
     return rot_fwd<Z, ELEM, (Z - S) % Z>(zb);
 }
 
+// The NEXT frame's channel LLRs, fetched straight into an LDS staging area [NB][64 lanes] while the
+// current frame is decoded (single-wave workgroups, float LLRs).  global_load_lds moves the data
+// without holding registers while it is on its way; without it a wave idles for a memory round
+// trip at the start of every frame.  Written as instructions: the compiler's own bookkeeping for
+// LDS-DMA makes every later LDS store wait for the transfer, which would put the round trip back
+// on the critical path.  The caller waits (s_waitcnt 0) before reading the area and again before
+// refilling it.  Lanes without a frame read frame 0, which exists.
+// Worth it only while LDS is not what limits residency: with the staging area at least twelve
+// single-wave workgroups (three per SIMD) must still fit a compute unit.
+template <class C, typename TL>
+constexpr bool llr_prefetch_pays(int lds_bytes)
+{
+    return sizeof(TL) == 4 && (160 * 1024) / (lds_bytes + C::NB * 256) >= 12;
+}
+template <class C, int F>
+__device__ __forceinline__ void llr_prefetch(float *stage, const float *llr, long long group, long long frames,
+                                             bool lane_on, int f, int z)
+{
+    const long long fr = group * F + f;
+    const float *src = llr + (lane_on && fr < frames ? fr : 0) * (C::NB * C::Z) + z;
+    const unsigned base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) float *)stage;
+    static_for<0, C::NB>([&](auto bc) {
+        const float *from = src + bc * C::Z;
+        const unsigned to = base + bc * 256u;
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off"
+                     :: "v"(from), "s"(to) : "memory");  // M0 is reserved: the compiler reloads it before each use of its own
+    });
+}
+template <class C, int F>
+__device__ __forceinline__ void llr_prefetch(float *, const double *, long long, long long, bool, int, int) {}
+
 // Hard decisions as ballots: one 64-bit lane mask per block column; the syndrome of a block row is
 // the XOR of those masks rotated by the circulant shifts (scalar instructions only).
 template <int Z, int F>
