@@ -310,6 +310,35 @@ PACKAGED = {
 }
 
 
+#: circulant tables registered by the user (``python -m ldpc_amd.add_code``): name -> file under
+#: ldpc_amd/data holding Z, mb, nb, edge_row, edge_col, edge_shift.  Listed in user_codes.json;
+#: each gets a compiled-in kernel at the next build, like the packaged codes.
+USER_REGISTRY = os.path.join(_DATA_DIR, "user_codes.json")
+
+
+def user_codes() -> dict:
+    """name -> {"file": ..., "slots": frames per workgroup} of the registered circulant tables."""
+    import json
+    if not os.path.exists(USER_REGISTRY):
+        return {}
+    with open(USER_REGISTRY) as f:
+        return json.load(f)
+
+
+def save_qc_npz(path: str, qc: QCStructure) -> None:
+    order = np.lexsort((qc.edge_shift, qc.edge_col, qc.edge_row))
+    np.savez_compressed(path, Z=np.int32(qc.Z), mb=np.int32(qc.mb), nb=np.int32(qc.nb),
+                        edge_row=np.asarray(qc.edge_row, np.int32)[order],
+                        edge_col=np.asarray(qc.edge_col, np.int32)[order],
+                        edge_shift=np.asarray(qc.edge_shift, np.int32)[order])
+
+
+def load_qc_npz(path: str) -> QCStructure:
+    with np.load(path, allow_pickle=False) as d:
+        return QCStructure(int(d["Z"]), int(d["mb"]), int(d["nb"]), d["edge_row"].astype(np.int32),
+                           d["edge_col"].astype(np.int32), d["edge_shift"].astype(np.int32))
+
+
 def save_code_npz(path: str, H: np.ndarray, G: Optional[np.ndarray] = None) -> None:
     H = (np.asarray(H) != 0).astype(np.uint8)
     rows, cols = np.nonzero(H)
@@ -348,7 +377,11 @@ def load_packaged(name: str) -> CompiledCode:
     if name in _cache:
         return _cache[name]
     if name not in PACKAGED:
-        raise KeyError(f"unknown packaged code {name!r}; have {sorted(PACKAGED)}")
+        reg = user_codes()
+        if name in reg:
+            _cache[name] = compile_qc(load_qc_npz(os.path.join(_DATA_DIR, reg[name]["file"])), name)
+            return _cache[name]
+        raise KeyError(f"unknown packaged code {name!r}; have {sorted(PACKAGED) + sorted(reg)}")
     if name not in _cache:
         fname, trunc = PACKAGED[name]
         H, _ = load_code_npz(os.path.join(_DATA_DIR, fname))

@@ -106,3 +106,25 @@ def test_syndrome_matches_dense_product():
     rng = np.random.default_rng(2)
     x = rng.integers(0, 2, size=(5, c.n))
     assert np.array_equal(c.syndrome(x), (x @ c.dense().T.astype(int)) % 2)
+
+
+def test_user_registered_circulant_table(tmp_path, monkeypatch):
+    """ldpc_amd.add_code: a caller's table becomes loadable by name and appears in the generated header."""
+    from ldpc_amd import add_code, gen_codes, nr_bg1
+    monkeypatch.setattr(codes, "_DATA_DIR", str(tmp_path))
+    monkeypatch.setattr(codes, "USER_REGISTRY", str(tmp_path / "user_codes.json"))
+    qc = nr_bg1.build(Z=96, seed=6)
+    table = tmp_path / "mine.npz"
+    codes.save_qc_npz(str(table), qc)
+    rec = add_code.register("my_bg1_z96", str(table))
+    assert rec["slots"] == 1 and rec["Z"] == 96 and "my_bg1_z96" in codes.user_codes()
+    code = codes.load_packaged("my_bg1_z96")
+    assert (code.m, code.n, code.qc.Z) == (46 * 96, 68 * 96, 96)
+    assert gen_codes.specialised()["my_bg1_z96"] == (1,)
+    text = gen_codes.describe("my_bg1_z96")
+    assert "struct Code_my_bg1_z96" in text and "Z = 96, MB = 46, NB = 68, EB = 316" in text
+    with pytest.raises(ValueError):
+        add_code.register("ccsds512", str(table))
+    add_code.remove("my_bg1_z96")
+    codes._cache.pop("my_bg1_z96", None)
+    assert "my_bg1_z96" not in codes.user_codes()
