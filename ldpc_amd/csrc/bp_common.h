@@ -76,6 +76,9 @@ hipError_t launch_spec_lnms(int spec_id, const ldpc_decode_config &cfg, int comp
 // decode_spec_spa.hip: sum-product rules R2-R4, specialised for the small packaged codes
 hipError_t launch_spec_spa(int spec_id, const ldpc_decode_config &cfg, int compute_dtype, const Launch &io,
                            int num_cus, const char **kernel_name, bool *supported);
+// decode_spec_r1w.hip: rule R1 with several waves per frame group, for the larger packaged codes
+hipError_t launch_spec_r1w(int spec_id, const ldpc_decode_config &cfg, int compute_dtype, const Launch &io,
+                           int num_cus, const char **kernel_name, bool *supported);
 // decode_qc_lnms.hip: the same rule for any circulant code, base graph in device tables
 hipError_t launch_qc_lnms(const QcDev &code, const ldpc_decode_config &cfg, int compute_dtype, const Launch &io,
                           int num_cus, void **workspace, size_t *workspace_bytes, const char **kernel_name,

@@ -1,0 +1,343 @@
+// Rule R1 (bpsk.py:154-260, extrinsic normalised min-sum) on the compile-time path for codes whose
+// per-frame state is too large for the one-wave-per-workgroup kernel of decode_spec.hip to keep a
+// compute unit busy (802.11n in double: three waves per CU; the BG2-shaped 5G matrix: one or two).
+//
+// W waves share the F frame slots of a workgroup.  Every wave maps its lanes to (slot, z) in the
+// same way; every wave owns a share of the block rows in the check phase and a share of the block
+// columns in the variable phase (balanced by edge count at compile time), each share as its own
+// unrolled code path.  Per-variable state (channel LLR, posterior, own variable-to-check messages)
+// sits in registers indexed by the wave's
+// LOCAL column number, so a wave only pays registers for its share of the graph.
+//
+// LDS per slot:  qv [EB][Z]  variable-to-check messages in variable order (written linearly by the
+//                            variable, read rotated by the check)
+//                cs [MB][Z]  per check (m1, m2) with the sign parity in both sign bits
+//                hb [NB][Z]  hard decisions, one byte each (`0 if b > 0 else 1`, bpsk.py:240-243)
+// One iteration: check phase (which also forms the parity of the current hard decisions - the
+// syndrome test at the top of the iteration, bpsk.py:205-209) | barrier | slots whose syndrome is
+// zero stop here, before their update | variable phase | barrier.
+#include "spec_common.h"
+
+namespace ldpc {
+
+// Which wave owns which block row / block column: longest-first greedy balancing of the edge counts
+// (plus one unit of fixed cost per row or column), evaluated at compile time.  Each phase ends in a
+// barrier, so an iteration costs the most loaded wave's share.
+template <int W, int N>
+struct R1wAssign {
+    int cnt[W];
+    int item[W][N];
+    int edge0[W][N + 1];  // running edge count in front of the wave's j-th item
+    int max_cnt, max_edges;
+};
+
+template <int W, int N>
+constexpr R1wAssign<W, N> r1w_balance(const int *ptr)
+{
+    R1wAssign<W, N> a{};
+    int load[W] = {};
+    bool used[N] = {};
+    for (int step = 0; step < N; ++step) {
+        int best = -1, bw = -1;
+        for (int i = 0; i < N; ++i) {
+            const int wgt = ptr[i + 1] - ptr[i];
+            if (!used[i] && wgt > bw) { best = i; bw = wgt; }
+        }
+        used[best] = true;
+        int w = 0;
+        for (int v = 1; v < W; ++v)
+            if (load[v] < load[w]) w = v;
+        load[w] += bw + 1;
+        a.item[w][a.cnt[w]++] = best;
+    }
+    for (int w = 0; w < W; ++w) {
+        for (int i = 1; i < a.cnt[w]; ++i)  // ascending inside a wave
+            for (int j = i; j > 0 && a.item[w][j - 1] > a.item[w][j]; --j) {
+                const int t = a.item[w][j]; a.item[w][j] = a.item[w][j - 1]; a.item[w][j - 1] = t;
+            }
+        int e = 0;
+        for (int j = 0; j < a.cnt[w]; ++j) {
+            a.edge0[w][j] = e;
+            e += ptr[a.item[w][j] + 1] - ptr[a.item[w][j]];
+        }
+        a.edge0[w][a.cnt[w]] = e;
+        a.max_cnt = a.cnt[w] > a.max_cnt ? a.cnt[w] : a.max_cnt;
+        a.max_edges = e > a.max_edges ? e : a.max_edges;
+    }
+    return a;
+}
+
+template <class C, int W>
+struct R1wPlan {
+    static constexpr R1wAssign<W, C::NB> COLS = r1w_balance<W, C::NB>(C::col_ptr);
+    static constexpr R1wAssign<W, C::MB> ROWS = r1w_balance<W, C::MB>(C::row_ptr);
+    static constexpr int NBW = COLS.max_cnt;                           // columns of the busiest wave
+    static constexpr int QW = COLS.max_edges > 0 ? COLS.max_edges : 1;  // its edges
+    static constexpr int MBW = ROWS.max_cnt;
+};
+
+template <class C, typename T, int F>
+struct R1wLayout {
+    static constexpr int LANES = F * C::Z;  // must be <= 64: a wave covers all slots
+    static constexpr int QV_BYTES = C::EB * C::Z * (int)sizeof(T);
+    static constexpr int CS_BYTES = C::MB * C::Z * 2 * (int)sizeof(T);
+    static constexpr int HB_BYTES = ((C::NB * C::Z + 15) / 16) * 16;
+    static constexpr int SLOT_BYTES = ((QV_BYTES + CS_BYTES + HB_BYTES + 127) / 128) * 128 + (F > 1 ? 32 : 0);
+    static constexpr int FLAG_OFF = F * SLOT_BYTES;
+    static constexpr int LDS_BYTES = FLAG_OFF + 64;
+};
+
+template <class C, typename T, typename TL, int F, int W>
+__global__ void __launch_bounds__(64 * W)
+spec_r1w_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__restrict__ hard_out,
+                int *__restrict__ iters_out, uint8_t *__restrict__ conv_out, T *__restrict__ post_out)
+{
+    typedef R1wLayout<C, T, F> LY;
+    typedef R1wPlan<C, W> PL;
+    typedef typename SNum<T>::Pair Pair;
+    static_assert(LY::LANES <= 64, "a wave covers all slots");
+    constexpr int Z = C::Z, NB = C::NB, MB = C::MB, ST = sizeof(T), SP = 2 * sizeof(T);
+    constexpr int n = NB * Z, NBW = PL::NBW, QW = PL::QW, MBW = PL::MBW;
+    extern __shared__ __align__(16) unsigned char smem[];
+
+    const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+    const bool lane_on = lane < F * Z;
+    const int f = lane_on ? lane / Z : 0;
+    const int z = lane_on ? lane - f * Z : 0;
+    unsigned char *qv_b = smem + f * LY::SLOT_BYTES;          // [EB][Z] T
+    unsigned char *cs_b = qv_b + LY::QV_BYTES;                // [MB][Z] Pair
+    unsigned char *hb_b = cs_b + LY::CS_BYTES;                // [NB][Z] u8
+    int *flags = reinterpret_cast<int *>(smem + LY::FLAG_OFF);  // [2][8]: failed-syndrome flag per slot, double-buffered by iteration parity
+    const unsigned zb = (unsigned)z * ST, zp = (unsigned)z * SP, z1 = (unsigned)z;
+
+    const long long groups = (frames + F - 1) / F;
+    for (long long grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+        const long long frame = grp * F + f;
+        const bool active = lane_on && frame < frames;
+        T L[NBW], own[NBW], q[QW];
+        // ---- start: every edge carries the channel LLR (bpsk.py:170-177)
+        static_for<0, W>([&](auto w) {
+            if (wave == w) {
+                static_for<0, NBW>([&](auto j) {
+                    if constexpr (j < PL::COLS.cnt[w]) {
+                        constexpr int bc = PL::COLS.item[w][j];
+                        constexpr int k0 = C::col_ptr[bc], D = C::col_ptr[bc + 1] - k0, q0 = PL::COLS.edge0[w][j];
+                        const T l = active ? (T)llr[frame * n + bc * Z + z] : (T)0;
+                        L[j] = l;
+                        own[j] = l;
+                        if (lane_on) hb_b[bc * Z + z1] = (uint8_t)hard_bit<1>(l);  // idle lanes alias lane 0
+                        static_for<0, D>([&](auto k) {
+                            q[q0 + k] = l;
+                            if (lane_on) *reinterpret_cast<T *>(qv_b + (k0 + k) * Z * ST + zb) = l;
+                        });
+                    }
+                });
+            }
+        });
+        if (threadIdx.x < 16) flags[threadIdx.x] = 0;
+        __syncthreads();
+
+        bool done = !active;
+        int res_iters = g.early_exit ? g.max_iters - 1 : g.max_iters, res_conv = 0;
+        for (int t = 0;; ++t) {
+            const bool last = t == g.max_iters;
+            if (last && g.early_exit) break;  // no test after the last update (bpsk.py:200-248)
+            const bool want_syn = g.early_exit || last;
+            // ---- check nodes of this wave's block rows (bpsk.py:213-233) and the parity of the
+            //      current hard decisions
+            unsigned bad = 0;
+            if (!done) {
+                static_for<0, W>([&](auto w) {
+                    if (wave == w) {
+                        static_for<0, MBW>([&](auto i) {
+                            if constexpr (i < PL::ROWS.cnt[w]) {
+                                constexpr int br = PL::ROWS.item[w][i];
+                                constexpr int e0 = C::row_ptr[br], D = C::row_ptr[br + 1] - e0;
+                                T m1 = Lim<T>::inf(), m2 = Lim<T>::inf();
+                                unsigned sx = 0, par = 0;
+                                static_for<0, D>([&](auto p) {
+                                    constexpr int kpos = C::row_kpos[e0 + p], s = C::row_shift[e0 + p], bc = C::row_col[e0 + p];
+                                    const T v = *reinterpret_cast<const T *>(qv_b + kpos * Z * ST + rot_fwd<Z, ST, s>(zb));
+                                    if (want_syn) par ^= hb_b[bc * Z + rot_fwd<Z, 1, s>(z1)];
+                                    m2 = SNum<T>::second(m1, m2, v);
+                                    m1 = SNum<T>::min_abs(m1, v);
+                                    sx ^= SNum<T>::sign_word(v);
+                                });
+                                if constexpr (D < 2) { m1 = (T)0; m2 = (T)0; }  // bpsk.py:216
+                                if (!last)
+                                    *reinterpret_cast<Pair *>(cs_b + br * Z * SP + zp) =
+                                        SNum<T>::make(SNum<T>::with_sign(m1, sx), SNum<T>::with_sign(m2, sx));
+                                bad |= par;
+                            }
+                        });
+                    }
+                });
+            }
+            int *slot_bad = flags + (t & 1) * 8;
+            if (bad) slot_bad[f] = 1;
+            __syncthreads();
+            // the other buffer was last read one iteration ago; the next iteration's writes to it
+            // come after the barrier that closes this iteration
+            if (threadIdx.x < 8) flags[((t + 1) & 1) * 8 + threadIdx.x] = 0;
+            if (want_syn) {
+                const bool slot_ok = slot_bad[f] == 0;
+                if (last) {
+                    if (!done) res_conv = slot_ok ? 1 : 0;
+                    break;
+                }
+                if (!done && slot_ok) { res_iters = t; res_conv = 1; done = true; }  // bpsk.py:205-209
+                bool any_live = false;
+                static_for<0, F>([&](auto ff) { any_live |= slot_bad[ff] != 0; });
+                if (!any_live) break;  // every slot that was still running has just converged
+            }
+            // ---- variable nodes of this wave's block columns (bpsk.py:235-247)
+            if (!done) {
+                static_for<0, W>([&](auto w) {
+                    if (wave == w) {
+                        static_for<0, NBW>([&](auto j) {
+                            if constexpr (j < PL::COLS.cnt[w]) {
+                                constexpr int bc = PL::COLS.item[w][j];
+                                constexpr int k0 = C::col_ptr[bc], D = C::col_ptr[bc + 1] - k0, q0 = PL::COLS.edge0[w][j];
+                                T r[D > 0 ? D : 1], qn[D > 0 ? D : 1];
+                                unsigned off[D > 0 ? D : 1];
+                                static_for<0, D>([&](auto k) {
+                                    constexpr int br = C::col_row[k0 + k], s = C::col_shift[k0 + k];
+                                    const T qo = q[q0 + k];
+                                    off[k] = rot_bwd<Z, SP, s>(zp);
+                                    const Pair c = *reinterpret_cast<const Pair *>(cs_b + br * Z * SP + off[k]);
+                                    const T sel = t_abs(qo) == t_abs(c.x) ? c.y : c.x;
+                                    r[k] = SNum<T>::flip_sign(g.scale * sel, SNum<T>::sign_word(qo) & 0x80000000u);
+                                });
+                                bool sw[D > 0 ? D : 1];
+                                static_for<0, (D > 0 ? D - 1 : 0)>([&](auto k) {
+                                    if constexpr (C::col_pair[k0 + k] != 0) {  // lower check index first
+                                        sw[k] = off[k] > off[k + 1];
+                                        const T a = r[k], b = r[k + 1];
+                                        r[k] = sw[k] ? b : a;
+                                        r[k + 1] = sw[k] ? a : b;
+                                    }
+                                });
+                                T run = (T)0;
+                                static_for<0, D>([&](auto k) {
+                                    T ext = run;
+                                    static_for<k + 1, D>([&](auto kk) { ext += r[kk]; });
+                                    run += r[k];
+                                    qn[k] = L[j] + ext;
+                                });
+                                static_for<0, (D > 0 ? D - 1 : 0)>([&](auto k) {
+                                    if constexpr (C::col_pair[k0 + k] != 0) {
+                                        const T a = qn[k], b = qn[k + 1];
+                                        qn[k] = sw[k] ? b : a;
+                                        qn[k + 1] = sw[k] ? a : b;
+                                    }
+                                });
+                                static_for<0, D>([&](auto k) {
+                                    q[q0 + k] = qn[k];
+                                    *reinterpret_cast<T *>(qv_b + (k0 + k) * Z * ST + zb) = qn[k];
+                                });
+                                own[j] = L[j] + run;  // bpsk.py:237
+                                hb_b[bc * Z + z1] = (uint8_t)hard_bit<1>(own[j]);
+                            }
+                        });
+                    }
+                });
+            }
+            __syncthreads();
+        }
+        // ---- results: every wave writes its own columns
+        if (active) {
+            static_for<0, W>([&](auto w) {
+                if (wave == w) {
+                    static_for<0, NBW>([&](auto j) {
+                        if constexpr (j < PL::COLS.cnt[w]) {
+                            constexpr int bc = PL::COLS.item[w][j];
+                            hard_out[frame * n + bc * Z + z] = (uint8_t)hard_bit<1>(own[j]);
+                            if (post_out) post_out[frame * n + bc * Z + z] = own[j];
+                        }
+                    });
+                }
+            });
+            if (wave == 0 && z == 0) { iters_out[frame] = res_iters; conv_out[frame] = (uint8_t)res_conv; }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------ host
+template <class C, typename T, typename TL, int F, int W>
+static hipError_t launch_r1w(const ldpc_decode_config &cfg, const Launch &io, int num_cus, const char **name)
+{
+    typedef R1wLayout<C, T, F> LY;
+    Cfg<T> g;
+    g.rule = 1; g.max_iters = cfg.max_iters; g.early_exit = cfg.early_exit;
+    g.float_syndrome0 = 0; g.num_active_checks = -1; g.num_refresh_vars = -1;
+    g.scale = (T)cfg.scale; g.clip_tanh_arg = (T)0; g.clip_prod = (T)0; g.clip_post = (T)0;
+    auto k = spec_r1w_kernel<C, T, TL, F, W>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LY::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    int per_cu = 0;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k), 64 * W, LY::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    if (per_cu < 1) per_cu = 1;
+    const long long groups = (io.frames + F - 1) / F;
+    long long grid = (long long)num_cus * per_cu * 2;
+    if (grid > groups) grid = groups;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(64 * W), LY::LDS_BYTES, io.stream, g,
+                       reinterpret_cast<const TL *>(io.llr), io.frames, io.hard, io.iters, io.converged,
+                       reinterpret_cast<T *>(io.posterior));
+    *name = sizeof(T) == 8 ? "spec_r1w_f64" : "spec_r1w_f32";
+    return hipGetLastError();
+}
+
+// Which codes and arithmetic types take this kernel instead of the single-wave one: those whose
+// single-wave footprint leaves fewer than eight workgroups per compute unit, or whose base graph
+// is too large for it altogether; the multi-wave layout must itself fit LDS.
+template <class C, typename T, int F>
+constexpr bool r1w_wanted()
+{
+    constexpr int single = F * (C::EB * C::Z * (int)sizeof(T) + C::MB * C::Z * 2 * (int)sizeof(T));
+    return F * C::Z <= 64 && R1wLayout<C, T, F>::LDS_BYTES <= 160 * 1024 && C::EB <= 200 &&
+           (C::EB > 100 || (160 * 1024) / single < 8);
+}
+
+// Four waves per workgroup; eight when LDS holds a single workgroup per compute unit anyway.
+template <class C, typename T, int F>
+constexpr int r1w_waves() { return R1wLayout<C, T, F>::LDS_BYTES > 80 * 1024 ? 8 : 4; }
+
+template <class C, int F>
+static hipError_t launch_r1w_code(const ldpc_decode_config &cfg, int compute_dtype, const Launch &io, int num_cus,
+                                  const char **name, bool *supported)
+{
+    *supported = true;
+    if constexpr (r1w_wanted<C, double, F>()) {
+        constexpr int W = r1w_waves<C, double, F>();
+        if (compute_dtype == LDPC_F64) {
+            if (io.llr_dtype == LDPC_F64) return launch_r1w<C, double, double, F, W>(cfg, io, num_cus, name);
+            return launch_r1w<C, double, float, F, W>(cfg, io, num_cus, name);
+        }
+    }
+    if constexpr (r1w_wanted<C, float, F>()) {
+        constexpr int W = r1w_waves<C, float, F>();
+        if (compute_dtype == LDPC_F32 && io.llr_dtype == LDPC_F32)
+            return launch_r1w<C, float, float, F, W>(cfg, io, num_cus, name);
+    }
+    *supported = false;
+    return hipSuccess;
+}
+
+hipError_t launch_spec_r1w(int spec_id, const ldpc_decode_config &cfg, int compute_dtype, const Launch &io,
+                           int num_cus, const char **name, bool *supported)
+{
+    int id = 0;
+#define LDPC_LAUNCH(CODE, SLOTS)                                                                   \
+    if (spec_id == id) return launch_r1w_code<CODE, (SLOTS * CODE::Z <= 64 ? SLOTS : 1)>(cfg, compute_dtype, io, num_cus, name, supported); \
+    ++id;
+    LDPC_FOR_EACH_SPEC_CODE(LDPC_LAUNCH)
+#undef LDPC_LAUNCH
+    *supported = false;
+    return hipSuccess;
+}
+
+}  // namespace ldpc
