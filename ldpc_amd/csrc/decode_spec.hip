@@ -485,7 +485,7 @@ hipError_t launch_spec(int spec_id, const ldpc_decode_config &cfg, int compute_d
         return launch_spec_lnms(spec_id, cfg, compute_dtype, io, num_cus, name, supported);
     if (cfg.rule >= 2 && cfg.rule <= 4)  // decode_spec_spa.hip
         return launch_spec_spa(spec_id, cfg, compute_dtype, io, num_cus, name, supported);
-    if (cfg.rule == 1) {  // decode_spec_r1w.hip: codes too large for one wave per workgroup
+    if (cfg.rule == 0 || cfg.rule == 1) {  // decode_spec_r1w.hip: codes too large for one wave per workgroup
         hipError_t e = launch_spec_r1w(spec_id, cfg, compute_dtype, io, num_cus, name, supported);
         if (e != hipSuccess || *supported) return e;
     }

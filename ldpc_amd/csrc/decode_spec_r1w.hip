@@ -263,6 +263,174 @@ spec_r1w_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t 
     }
 }
 
+// ------------------------------------------------------------------------------------------ R0
+// Rule R0 (ldpc.py:137-227) with the same division of work.  Its variable-to-check message is the
+// posterior itself (ldpc.py:180-187 reads bitNodes), so LDS per slot only holds
+//     post [NB][Z]  posteriors      cs [MB][Z]  per check (m1, m2) with the sign parity
+// and the parity of the hard decisions `1 - signbit` is a by-product of the sign word of the check.
+template <class C, typename T, int F>
+struct R0wLayout {
+    static constexpr int LANES = F * C::Z;
+    static constexpr int POST_BYTES = C::NB * C::Z * (int)sizeof(T);
+    static constexpr int CS_BYTES = C::MB * C::Z * 2 * (int)sizeof(T);
+    static constexpr int SLOT_BYTES = ((POST_BYTES + CS_BYTES + 127) / 128) * 128 + (F > 1 ? 32 : 0);
+    static constexpr int FLAG_OFF = F * SLOT_BYTES;
+    static constexpr int LDS_BYTES = FLAG_OFF + 64;
+};
+
+template <class C, typename T, typename TL, int F, int W>
+__global__ void __launch_bounds__(64 * W)
+spec_r0w_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__restrict__ hard_out,
+                int *__restrict__ iters_out, uint8_t *__restrict__ conv_out, T *__restrict__ post_out)
+{
+    typedef R0wLayout<C, T, F> LY;
+    typedef R1wPlan<C, W> PL;
+    typedef typename SNum<T>::Pair Pair;
+    static_assert(LY::LANES <= 64, "a wave covers all slots");
+    constexpr int Z = C::Z, NB = C::NB, ST = sizeof(T), SP = 2 * sizeof(T);
+    constexpr int n = NB * Z, NBW = PL::NBW, MBW = PL::MBW;
+    extern __shared__ __align__(16) unsigned char smem[];
+
+    const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+    const bool lane_on = lane < F * Z;
+    const int f = lane_on ? lane / Z : 0;
+    const int z = lane_on ? lane - f * Z : 0;
+    unsigned char *post_b = smem + f * LY::SLOT_BYTES;  // [NB][Z] T
+    unsigned char *cs_b = post_b + LY::POST_BYTES;      // [MB][Z] Pair
+    int *flags = reinterpret_cast<int *>(smem + LY::FLAG_OFF);  // [2][8], as in the R1 kernel
+    const unsigned zb = (unsigned)z * ST, zp = (unsigned)z * SP;
+
+    const long long groups = (frames + F - 1) / F;
+    for (long long grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+        const long long frame = grp * F + f;
+        const bool active = lane_on && frame < frames;
+        T L[NBW], own[NBW];
+        static_for<0, W>([&](auto w) {
+            if (wave == w) {
+                static_for<0, NBW>([&](auto j) {
+                    if constexpr (j < PL::COLS.cnt[w]) {
+                        constexpr int bc = PL::COLS.item[w][j];
+                        // + 0.0 turns -0.0 into +0.0: from here on "negative" is exactly "sign bit set"
+                        const T l = (active ? (T)llr[frame * n + bc * Z + z] : (T)0) + (T)0;
+                        L[j] = l;
+                        own[j] = l;  // ldpc.py:154
+                        if (lane_on) *reinterpret_cast<T *>(post_b + bc * Z * ST + zb) = l;  // idle lanes alias lane 0
+                    }
+                });
+            }
+        });
+        if (threadIdx.x < 16) flags[threadIdx.x] = 0;
+        __syncthreads();
+
+        bool done = !active, float_hard = false;
+        int res_iters = g.early_exit ? g.max_iters - 1 : g.max_iters, res_conv = 0;
+        for (int t = 0;; ++t) {
+            const bool last = t == g.max_iters;
+            if (last && g.early_exit) break;
+            const bool want_syn = g.early_exit || last;
+            const bool float_check = t == 0 && g.float_syndrome0 && g.early_exit;  // ldpc.py:158,165
+            // ---- check nodes of this wave's block rows (ldpc.py:175-187) and the syndrome
+            unsigned bad = 0;
+            if (!done) {
+                static_for<0, W>([&](auto w) {
+                    if (wave == w) {
+                        static_for<0, MBW>([&](auto i) {
+                            if constexpr (i < PL::ROWS.cnt[w]) {
+                                constexpr int br = PL::ROWS.item[w][i];
+                                constexpr int e0 = C::row_ptr[br], D = C::row_ptr[br + 1] - e0;
+                                T m1 = Lim<T>::inf(), m2 = Lim<T>::inf(), fsum = (T)0;
+                                unsigned sx = 0;
+                                static_for<0, D>([&](auto p) {
+                                    constexpr int bc = C::row_col[e0 + p], s = C::row_shift[e0 + p];
+                                    const T b = *reinterpret_cast<const T *>(post_b + bc * Z * ST + rot_fwd<Z, ST, s>(zb));
+                                    m2 = SNum<T>::second(m1, m2, b);
+                                    m1 = SNum<T>::min_abs(m1, b);
+                                    sx ^= SNum<T>::sign_word(b);
+                                    fsum += b;
+                                });
+                                if constexpr (D < 2) { m1 = (T)0; m2 = (T)0; }  // ldpc.py:178
+                                if (!last)
+                                    *reinterpret_cast<Pair *>(cs_b + br * Z * SP + zp) =
+                                        SNum<T>::make(SNum<T>::with_sign(m1, sx), SNum<T>::with_sign(m2, sx));
+                                if (float_check) bad |= !(t_fmod(fsum, (T)2) == (T)0);
+                                else bad |= ((unsigned)D ^ (sx >> 31)) & 1u;  // parity of the hard bits 1 - signbit
+                            }
+                        });
+                    }
+                });
+            }
+            int *slot_bad = flags + (t & 1) * 8;
+            if (bad && want_syn) slot_bad[f] = 1;
+            __syncthreads();
+            if (threadIdx.x < 8) flags[((t + 1) & 1) * 8 + threadIdx.x] = 0;
+            if (want_syn) {
+                const bool slot_ok = slot_bad[f] == 0;
+                if (last) {
+                    if (!done) res_conv = slot_ok ? 1 : 0;
+                    break;
+                }
+                if (!done && slot_ok) { res_iters = t; res_conv = 1; done = true; float_hard = float_check; }  // ldpc.py:165-170
+                bool any_live = false;
+                static_for<0, F>([&](auto ff) { any_live |= slot_bad[ff] != 0; });
+                if (!any_live) break;
+            }
+            // ---- variable nodes of this wave's block columns (ldpc.py:173,188-196)
+            if (!done) {
+                static_for<0, W>([&](auto w) {
+                    if (wave == w) {
+                        static_for<0, NBW>([&](auto j) {
+                            if constexpr (j < PL::COLS.cnt[w]) {
+                                constexpr int bc = PL::COLS.item[w][j];
+                                constexpr int k0 = C::col_ptr[bc], D = C::col_ptr[bc + 1] - k0;
+                                const unsigned so = SNum<T>::sign_word(own[j]) & 0x80000000u;
+                                const T ao = t_abs(own[j]);
+                                T r[D > 0 ? D : 1];
+                                unsigned off[D > 0 ? D : 1];
+                                static_for<0, D>([&](auto k) {
+                                    constexpr int br = C::col_row[k0 + k], s = C::col_shift[k0 + k];
+                                    off[k] = rot_bwd<Z, SP, s>(zp);
+                                    const Pair c = *reinterpret_cast<const Pair *>(cs_b + br * Z * SP + off[k]);
+                                    r[k] = SNum<T>::flip_sign(ao == t_abs(c.x) ? c.y : c.x, so);
+                                });
+                                static_for<0, (D > 0 ? D - 1 : 0)>([&](auto k) {
+                                    if constexpr (C::col_pair[k0 + k] != 0) {  // lower check index first
+                                        const bool sw = off[k] > off[k + 1];
+                                        const T a = r[k], b = r[k + 1];
+                                        r[k] = sw ? b : a;
+                                        r[k + 1] = sw ? a : b;
+                                    }
+                                });
+                                T sum = (T)0;
+                                static_for<0, D>([&](auto k) { sum += r[k]; });
+                                own[j] = g.scale * (sum + L[j]);  // ldpc.py:196
+                                *reinterpret_cast<T *>(post_b + bc * Z * ST + zb) = own[j];
+                            }
+                        });
+                    }
+                });
+            }
+            __syncthreads();
+        }
+        if (active) {
+            static_for<0, W>([&](auto w) {
+                if (wave == w) {
+                    static_for<0, NBW>([&](auto j) {
+                        if constexpr (j < PL::COLS.cnt[w]) {
+                            constexpr int bc = PL::COLS.item[w][j];
+                            const T v = own[j];
+                            hard_out[frame * n + bc * Z + z] =
+                                float_hard ? (v == (T)0 ? 0 : (v == (T)1 ? 1 : 2)) : (uint8_t)hard_bit<0>(v);
+                            if (post_out) post_out[frame * n + bc * Z + z] = v;
+                        }
+                    });
+                }
+            });
+            if (wave == 0 && z == 0) { iters_out[frame] = res_iters; conv_out[frame] = (uint8_t)res_conv; }
+        }
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------------------ host
 template <class C, typename T, typename TL, int F, int W>
 static hipError_t launch_r1w(const ldpc_decode_config &cfg, const Launch &io, int num_cus, const char **name)
@@ -327,12 +495,61 @@ static hipError_t launch_r1w_code(const ldpc_decode_config &cfg, int compute_dty
     return hipSuccess;
 }
 
+template <class C, typename T, typename TL, int F, int W>
+static hipError_t launch_r0w(const ldpc_decode_config &cfg, const Launch &io, int num_cus, const char **name)
+{
+    typedef R0wLayout<C, T, F> LY;
+    Cfg<T> g;
+    g.rule = 0; g.max_iters = cfg.max_iters; g.early_exit = cfg.early_exit;
+    g.float_syndrome0 = cfg.float_syndrome0; g.num_active_checks = -1; g.num_refresh_vars = -1;
+    g.scale = (T)cfg.scale; g.clip_tanh_arg = (T)0; g.clip_prod = (T)0; g.clip_post = (T)0;
+    auto k = spec_r0w_kernel<C, T, TL, F, W>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LY::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    int per_cu = 0;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k), 64 * W, LY::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    if (per_cu < 1) per_cu = 1;
+    const long long groups = (io.frames + F - 1) / F;
+    long long grid = (long long)num_cus * per_cu * 2;
+    if (grid > groups) grid = groups;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(64 * W), LY::LDS_BYTES, io.stream, g,
+                       reinterpret_cast<const TL *>(io.llr), io.frames, io.hard, io.iters, io.converged,
+                       reinterpret_cast<T *>(io.posterior));
+    *name = sizeof(T) == 8 ? "spec_r0w_f64" : "spec_r0w_f32";
+    return hipGetLastError();
+}
+
+// Rule R0 comes here only for base graphs the single-wave kernel does not unroll (more than 100 edges).
+template <class C, int F>
+static hipError_t launch_r0w_code(const ldpc_decode_config &cfg, int compute_dtype, const Launch &io, int num_cus,
+                                  const char **name, bool *supported)
+{
+    *supported = true;
+    if constexpr (F * C::Z <= 64 && C::EB > 100 && C::EB <= 200 && R0wLayout<C, double, F>::LDS_BYTES <= 160 * 1024) {
+        constexpr int W = 4;
+        if (compute_dtype == LDPC_F64) {
+            if (io.llr_dtype == LDPC_F64) return launch_r0w<C, double, double, F, W>(cfg, io, num_cus, name);
+            return launch_r0w<C, double, float, F, W>(cfg, io, num_cus, name);
+        }
+        if (io.llr_dtype == LDPC_F32) return launch_r0w<C, float, float, F, W>(cfg, io, num_cus, name);
+    }
+    *supported = false;
+    return hipSuccess;
+}
+
 hipError_t launch_spec_r1w(int spec_id, const ldpc_decode_config &cfg, int compute_dtype, const Launch &io,
                            int num_cus, const char **name, bool *supported)
 {
     int id = 0;
 #define LDPC_LAUNCH(CODE, SLOTS)                                                                   \
-    if (spec_id == id) return launch_r1w_code<CODE, (SLOTS * CODE::Z <= 64 ? SLOTS : 1)>(cfg, compute_dtype, io, num_cus, name, supported); \
+    if (spec_id == id) {                                                                           \
+        constexpr int F = SLOTS * CODE::Z <= 64 ? SLOTS : 1;                                       \
+        if (cfg.rule == 0) return launch_r0w_code<CODE, F>(cfg, compute_dtype, io, num_cus, name, supported); \
+        return launch_r1w_code<CODE, F>(cfg, compute_dtype, io, num_cus, name, supported);         \
+    }                                                                                              \
     ++id;
     LDPC_FOR_EACH_SPEC_CODE(LDPC_LAUNCH)
 #undef LDPC_LAUNCH
