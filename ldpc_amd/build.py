@@ -32,9 +32,10 @@ UNITS += [("decode_qc_r0.o", "decode_qc_r0.hip", []), ("decode_spec.o", "decode_
           ("decode_lnms.o", "decode_lnms.hip", []),
           ("decode_qc_lnms.o", "decode_qc_lnms.hip", []),
           ("decode_spec_spa.o", "decode_spec_spa.hip", []),
-          ("decode_spec_r1w.o", "decode_spec_r1w.hip", [])]
+          ("decode_spec_r1w.o", "decode_spec_r1w.hip", []),
+          ("decode_spec_spaw.o", "decode_spec_spaw.hip", [])]
 UNITS += [(f"decode_qc_r{k}.o", "decode_qc.hip", [f"-DLDPC_QC_RULE={k}"]) for k in range(1, 5)]
-HEADERS = ["bp_common.h", "bp_math.h", "spec_common.h", os.path.join("gen", "codes_gen.h"),
+HEADERS = ["bp_common.h", "bp_math.h", "spec_common.h", "spec_r1w_plan.h", os.path.join("gen", "codes_gen.h"),
            os.path.join(ROOT, "include", "ldpc_amd.h")]
 
 

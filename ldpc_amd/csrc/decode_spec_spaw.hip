@@ -1,0 +1,312 @@
+// Sum-product rules R2, R3, R4 on the compile-time path with several waves per frame group, for
+// the packaged codes the single-wave kernel of decode_spec_spa.hip does not serve: base graphs of
+// more than 100 edges (the BG2-shaped 5G matrix) and codes whose messages leave room for fewer
+// than eight single-wave workgroups per compute unit (802.11n in double).
+//
+// Division of work as in decode_spec_r1w.hip: W waves share the F frame slots, every wave owns a
+// balanced share of the block rows (check phase) and of the block columns (variable phase).
+// LDS per slot:  msg [EB][Z]  one message per edge in check order, updated in place by both phases
+//                             (see decode_spec_spa.hip)
+//                hb  [NB][Z]  hard decisions `not (b > 0)`, one byte each
+// One iteration: parity of the hard decisions over the wave's rows (bpsk.py:311-316) | barrier |
+// slots with a zero syndrome stop | check phase | barrier | variable phase | barrier.
+//
+// R2  bpsk.py:263-387     R3  channel.py:402-513     R4  channel.py:260-398
+#include "spec_r1w_plan.h"
+
+namespace ldpc {
+
+template <class C, typename T, int F>
+struct SpawLayout {
+    static constexpr int LANES = F * C::Z;
+    static constexpr int MSG_BYTES = C::EB * C::Z * (int)sizeof(T);
+    static constexpr int HB_BYTES = ((C::NB * C::Z + 15) / 16) * 16;
+    static constexpr int SLOT_BYTES = ((MSG_BYTES + HB_BYTES + 127) / 128) * 128 + (F > 1 ? 32 : 0);
+    static constexpr int FLAG_OFF = F * SLOT_BYTES;
+    static constexpr int LDS_BYTES = FLAG_OFF + 64;
+};
+
+template <int RULE, class C, typename T, typename TL, int F, int W>
+__global__ void __launch_bounds__(64 * W)
+spec_spaw_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__restrict__ hard_out,
+                 int *__restrict__ iters_out, uint8_t *__restrict__ conv_out, T *__restrict__ post_out)
+{
+    typedef SpawLayout<C, T, F> LY;
+    typedef R1wPlan<C, W> PL;
+    static_assert(LY::LANES <= 64, "a wave covers all slots");
+    constexpr int Z = C::Z, NB = C::NB, ST = sizeof(T);
+    constexpr int n = NB * Z, NBW = PL::NBW, MBW = PL::MBW;
+    extern __shared__ __align__(16) unsigned char smem[];
+
+    const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+    const bool lane_on = lane < F * Z;
+    const int f = lane_on ? lane / Z : 0;
+    const int z = lane_on ? lane - f * Z : 0;
+    unsigned char *msg_b = smem + f * LY::SLOT_BYTES;  // [EB][Z] T
+    unsigned char *hb_b = msg_b + LY::MSG_BYTES;       // [NB][Z] u8
+    int *flags = reinterpret_cast<int *>(smem + LY::FLAG_OFF);  // [2][8]: failed-syndrome flag per slot, by iteration parity
+    const unsigned zb = (unsigned)z * ST, z1 = (unsigned)z;
+
+    const long long groups = (frames + F - 1) / F;
+    for (long long grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+        const long long frame = grp * F + f;
+        const bool active = lane_on && frame < frames;
+        T L[NBW], own[NBW];
+        static_for<0, W>([&](auto w) {
+            if (wave == w) {
+                static_for<0, NBW>([&](auto j) {
+                    if constexpr (j < PL::COLS.cnt[w]) {
+                        constexpr int bc = PL::COLS.item[w][j];
+                        constexpr int k0 = C::col_ptr[bc], D = C::col_ptr[bc + 1] - k0;
+                        const T l = active ? (T)llr[frame * n + bc * Z + z] : (T)0;
+                        L[j] = l;
+                        own[j] = l;
+                        if (lane_on) hb_b[bc * Z + z1] = (uint8_t)!(l > (T)0);  // idle lanes alias lane 0
+                        static_for<0, D>([&](auto k) {  // bpsk.py:299-306: every edge starts with the channel LLR
+                            constexpr int e = C::col_slot[k0 + k], s = C::col_shift[k0 + k];
+                            if (lane_on) *reinterpret_cast<T *>(msg_b + e * Z * ST + rot_bwd<Z, ST, s>(zb)) = l;
+                        });
+                    }
+                });
+            }
+        });
+        if (threadIdx.x < 16) flags[threadIdx.x] = 0;
+        __syncthreads();
+
+        bool done = !active;
+        int res_iters = g.early_exit ? g.max_iters - 1 : g.max_iters, res_conv = 0;
+        for (int t = 0;; ++t) {
+            const bool last = t == g.max_iters;
+            if (last && g.early_exit) break;  // no test after the last update
+            if (g.early_exit || last) {
+                // ---- syndrome of the current hard decisions, this wave's block rows
+                unsigned bad = 0;
+                if (!done) {
+                    static_for<0, W>([&](auto w) {
+                        if (wave == w) {
+                            static_for<0, MBW>([&](auto i) {
+                                if constexpr (i < PL::ROWS.cnt[w]) {
+                                    constexpr int br = PL::ROWS.item[w][i];
+                                    constexpr int e0 = C::row_ptr[br], D = C::row_ptr[br + 1] - e0;
+                                    unsigned hv[D > 0 ? D : 1];
+                                    static_for<0, D>([&](auto p) {
+                                        constexpr int bc = C::row_col[e0 + p], s = C::row_shift[e0 + p];
+                                        hv[p] = hb_b[bc * Z + rot_fwd<Z, 1, s>(z1)];
+                                    });
+                                    unsigned par = 0;
+                                    static_for<0, D>([&](auto p) { par ^= hv[p]; });
+                                    bad |= par;
+                                }
+                            });
+                        }
+                    });
+                }
+                int *slot_bad = flags + (t & 1) * 8;
+                if (bad) slot_bad[f] = 1;
+                __syncthreads();
+                // the other buffer was last read one iteration ago; its next writes come after the
+                // barriers of this iteration
+                if (threadIdx.x < 8) flags[((t + 1) & 1) * 8 + threadIdx.x] = 0;
+                const bool slot_ok = slot_bad[f] == 0;
+                if (last) {
+                    if (!done) res_conv = slot_ok ? 1 : 0;
+                    break;
+                }
+                if (!done && slot_ok) { res_iters = t; res_conv = 1; done = true; }
+                bool any_live = false;
+                static_for<0, F>([&](auto ff) { any_live |= slot_bad[ff] != 0; });
+                if (!any_live) break;
+            }
+            // ---- check nodes of this wave's block rows
+            if (!done) {
+                static_for<0, W>([&](auto w) {
+                    if (wave == w) {
+                        static_for<0, MBW>([&](auto i) {
+                            if constexpr (i < PL::ROWS.cnt[w]) {
+                                constexpr int br = PL::ROWS.item[w][i];
+                                constexpr int e0 = C::row_ptr[br], D = C::row_ptr[br + 1] - e0;
+                                T v[D > 0 ? D : 1];
+                                static_for<0, D>([&](auto p) { v[p] = *reinterpret_cast<const T *>(msg_b + (e0 + p) * Z * ST + zb); });
+                                if constexpr (RULE == 2 || RULE == 3) {  // bpsk.py:325-339, channel.py:471-474
+                                    T th[D > 0 ? D : 1], suf[D > 0 ? D : 1];
+                                    static_for<0, D>([&](auto p) { th[p] = spa_tanh_half(v[p], g.clip_tanh_arg); });
+                                    T run = (T)1;
+                                    static_for<0, D>([&](auto pp) { constexpr int p = D - 1 - pp; suf[p] = run; run *= th[p]; });
+                                    T pre = (T)1;
+                                    static_for<0, D>([&](auto p) {
+                                        *reinterpret_cast<T *>(msg_b + (e0 + p) * Z * ST + zb) =
+                                            spa_message(pre * suf[p], g.clip_prod, g.scale, RULE == 3);
+                                        pre *= th[p];
+                                    });
+                                } else {  // channel.py:332-352
+                                    T ph[D > 0 ? D : 1], suf[D > 0 ? D : 1];
+                                    unsigned neg = 0;
+                                    static_for<0, D>([&](auto p) {
+                                        neg |= (unsigned)(v[p] < (T)0) << p;  // 0 and 1e-9 count as +
+                                        ph[p] = phi(t_abs(v[p]));
+                                    });
+                                    T run = (T)0;
+                                    static_for<0, D>([&](auto pp) { constexpr int p = D - 1 - pp; suf[p] = run; run += ph[p]; });
+                                    T pre = (T)0;
+                                    static_for<0, D>([&](auto p) {
+                                        const bool negative = (__popc(neg & ~(1u << p)) & 1) != 0;
+                                        *reinterpret_cast<T *>(msg_b + (e0 + p) * Z * ST + zb) = phi_message(pre + suf[p], negative);
+                                        pre += ph[p];
+                                    });
+                                }
+                            }
+                        });
+                    }
+                });
+            }
+            __syncthreads();
+            // ---- variable nodes of this wave's block columns (bpsk.py:346-375, channel.py:358-367, 480-491)
+            if (!done) {
+                static_for<0, W>([&](auto w) {
+                    if (wave == w) {
+                        static_for<0, NBW>([&](auto j) {
+                            if constexpr (j < PL::COLS.cnt[w]) {
+                                constexpr int bc = PL::COLS.item[w][j];
+                                constexpr int k0 = C::col_ptr[bc], D = C::col_ptr[bc + 1] - k0;
+                                T r[D > 0 ? D : 1], qn[D > 0 ? D : 1];
+                                unsigned off[D > 0 ? D : 1];
+                                static_for<0, D>([&](auto k) {
+                                    constexpr int e = C::col_slot[k0 + k], s = C::col_shift[k0 + k];
+                                    off[k] = e * Z * ST + rot_bwd<Z, ST, s>(zb);
+                                    r[k] = *reinterpret_cast<const T *>(msg_b + off[k]);
+                                });
+                                bool sw[D > 0 ? D : 1];
+                                static_for<0, (D > 0 ? D - 1 : 0)>([&](auto k) {
+                                    if constexpr (C::col_pair[k0 + k] != 0) {  // two circulants in one block: lower check index first
+                                        constexpr int s0 = C::col_shift[k0 + k], s1 = C::col_shift[k0 + k + 1];
+                                        sw[k] = rot_bwd<Z, ST, s0>(zb) > rot_bwd<Z, ST, s1>(zb);
+                                        const T a = r[k], b = r[k + 1];
+                                        r[k] = sw[k] ? b : a;
+                                        r[k + 1] = sw[k] ? a : b;
+                                    }
+                                });
+                                T run = (T)0;
+                                static_for<0, D>([&](auto k) {
+                                    T ext = run;
+                                    static_for<k + 1, D>([&](auto kk) { ext += r[kk]; });
+                                    run += r[k];
+                                    qn[k] = L[j] + ext;
+                                });
+                                static_for<0, (D > 0 ? D - 1 : 0)>([&](auto k) {
+                                    if constexpr (C::col_pair[k0 + k] != 0) {
+                                        const T a = qn[k], b = qn[k + 1];
+                                        qn[k] = sw[k] ? b : a;
+                                        qn[k + 1] = sw[k] ? a : b;
+                                    }
+                                });
+                                static_for<0, D>([&](auto k) { *reinterpret_cast<T *>(msg_b + off[k]) = qn[k]; });
+                                T b = L[j] + run;
+                                if (g.clip_post > (T)0) b = clip(b, -g.clip_post, g.clip_post);
+                                own[j] = b;
+                                hb_b[bc * Z + z1] = (uint8_t)!(b > (T)0);
+                            }
+                        });
+                    }
+                });
+            }
+            __syncthreads();
+        }
+        if (active) {
+            static_for<0, W>([&](auto w) {
+                if (wave == w) {
+                    static_for<0, NBW>([&](auto j) {
+                        if constexpr (j < PL::COLS.cnt[w]) {
+                            constexpr int bc = PL::COLS.item[w][j];
+                            hard_out[frame * n + bc * Z + z] = (uint8_t)hard_bit<RULE>(own[j]);
+                            if (post_out) post_out[frame * n + bc * Z + z] = own[j];
+                        }
+                    });
+                }
+            });
+            if (wave == 0 && z == 0) { iters_out[frame] = res_iters; conv_out[frame] = (uint8_t)res_conv; }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------ host
+template <int RULE, class C, typename T, typename TL, int F, int W>
+static hipError_t launch_spaw(const ldpc_decode_config &cfg, const Launch &io, int num_cus, const char **name)
+{
+    typedef SpawLayout<C, T, F> LY;
+    Cfg<T> g;
+    g.rule = RULE; g.max_iters = cfg.max_iters; g.early_exit = cfg.early_exit;
+    g.float_syndrome0 = 0; g.num_active_checks = -1; g.num_refresh_vars = -1;
+    g.scale = (T)cfg.scale; g.clip_tanh_arg = (T)cfg.clip_tanh_arg; g.clip_prod = (T)cfg.clip_prod;
+    g.clip_post = (T)cfg.clip_post;
+    auto k = spec_spaw_kernel<RULE, C, T, TL, F, W>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LY::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    int per_cu = 0;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k), 64 * W, LY::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    if (per_cu < 1) per_cu = 1;
+    const long long groups = (io.frames + F - 1) / F;
+    long long grid = (long long)num_cus * per_cu * 2;
+    if (grid > groups) grid = groups;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(64 * W), LY::LDS_BYTES, io.stream, g,
+                       reinterpret_cast<const TL *>(io.llr), io.frames, io.hard, io.iters, io.converged,
+                       reinterpret_cast<T *>(io.posterior));
+    *name = sizeof(T) == 8 ? "spec_spaw_f64" : "spec_spaw_f32";
+    return hipGetLastError();
+}
+
+// Codes and arithmetic types that come here: see the head of this file.
+template <class C, typename T, int F>
+constexpr bool spaw_wanted()
+{
+    constexpr int single = F * C::EB * C::Z * (int)sizeof(T);
+    return F * C::Z <= 64 && SpawLayout<C, T, F>::LDS_BYTES <= 160 * 1024 && C::EB <= 200 &&
+           (C::EB > 100 || (160 * 1024) / single < 8);
+}
+
+#ifndef LDPC_SPAW_WAVES
+#define LDPC_SPAW_WAVES 4
+#endif
+
+template <int RULE, class C, int F>
+static hipError_t launch_spaw_rule(const ldpc_decode_config &cfg, int compute_dtype, const Launch &io, int num_cus,
+                                   const char **name, bool *supported)
+{
+    constexpr int W = LDPC_SPAW_WAVES;
+    *supported = true;
+    if constexpr (spaw_wanted<C, double, F>()) {
+        if (compute_dtype == LDPC_F64) {
+            if (io.llr_dtype == LDPC_F64) return launch_spaw<RULE, C, double, double, F, W>(cfg, io, num_cus, name);
+            return launch_spaw<RULE, C, double, float, F, W>(cfg, io, num_cus, name);
+        }
+    }
+    if constexpr (spaw_wanted<C, float, F>()) {
+        if (compute_dtype == LDPC_F32 && io.llr_dtype == LDPC_F32)
+            return launch_spaw<RULE, C, float, float, F, W>(cfg, io, num_cus, name);
+    }
+    *supported = false;
+    return hipSuccess;
+}
+
+hipError_t launch_spec_spaw(int spec_id, const ldpc_decode_config &cfg, int compute_dtype, const Launch &io,
+                            int num_cus, const char **name, bool *supported)
+{
+    int id = 0;
+#define LDPC_LAUNCH(CODE, SLOTS)                                                                   \
+    if (spec_id == id) {                                                                           \
+        constexpr int F = SLOTS * CODE::Z <= 64 ? SLOTS : 1;                                       \
+        if (cfg.rule == 2) return launch_spaw_rule<2, CODE, F>(cfg, compute_dtype, io, num_cus, name, supported); \
+        if (cfg.rule == 3) return launch_spaw_rule<3, CODE, F>(cfg, compute_dtype, io, num_cus, name, supported); \
+        if (cfg.rule == 4) return launch_spaw_rule<4, CODE, F>(cfg, compute_dtype, io, num_cus, name, supported); \
+    }                                                                                              \
+    ++id;
+    LDPC_FOR_EACH_SPEC_CODE(LDPC_LAUNCH)
+#undef LDPC_LAUNCH
+    *supported = false;
+    return hipSuccess;
+}
+
+}  // namespace ldpc
