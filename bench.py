@@ -18,7 +18,7 @@ Rank 0 prints one JSON line.  Beside the headline value it carries
   valu_roofline vector instructions issued (counter pass on file) against the nominal issue rate
   cpu_baseline  the CPU restatement (oracle/bp_oracle.c, OpenMP) timed on a bounded sample of the
                 same LLRs on this host, which doubles as a parity check of that sample
-  other         secondary workloads (early exit at an operating SNR, float32, rule R1, NR BG1
+  other         secondary workloads (early exit at an operating SNR, float32, rules R1 and R3, BG2-shaped 5G matrix, NR BG1
                 Z=384 layered min-sum), aggregated over all ranks like the headline
 """
 import argparse
@@ -304,6 +304,17 @@ def other_workloads(code, G, dec, args, torch, dist, device, world, rank):
     run("BG1_Z384_LNMS_f32_fixed_10", bg1, enc1, dec1, "LNMS", "f32", -3.0, False, 16384, bg1.n - bg1.m)
     run("BG1_Z384_LNMS_f32_es_n0_-3dB", bg1, enc1, dec1, "LNMS", "f32", -3.0, True, 16384, bg1.n - bg1.m)
     run("BG1_Z384_LNMS_f32_es_n0_0dB", bg1, enc1, dec1, "LNMS", "f32", 0.0, True, 16384, bg1.n - bg1.m)
+    # sum-product (tanh rule of channel.py) on the headline code, and the flooding rules on the BG2-shaped
+    # 5G matrix of the reference (all-zero codeword: these rules are symmetric in the codeword)
+    run("R3_f32_fixed_10", code, G, dec, "R3", "f32", args.snr, False, frames // 4, k)
+    run("R3_f64_fixed_10", code, G, dec, "R3", "f64", args.snr, False, frames // 8, k)
+    bg2 = codes.load_packaged("nr_bg2_z40")
+    dec2 = Decoder(bg2)
+    k2 = bg2.n - bg2.m
+    for label, rule, dtype in [("BG2_Z40_R0_f64_fixed_10", "R0", "f64"), ("BG2_Z40_R0_f32_fixed_10", "R0", "f32"),
+                               ("BG2_Z40_R1_f64_fixed_10", "R1", "f64"), ("BG2_Z40_R1_f32_fixed_10", "R1", "f32"),
+                               ("BG2_Z40_R3_f32_fixed_10", "R3", "f32")]:
+        run(label, bg2, None, dec2, rule, dtype, -2.0, False, 32768, k2)
     return res
 
 

@@ -24,17 +24,19 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-I", os.path.join(ROOT, "include"), "-I", CSRC]
 
 #: (object name, source, extra flags)
-UNITS = [("ldpc_abi.o", "ldpc_abi.hip", []),
-         ("decode_csr.o", "decode_csr.hip", []),
-         ("count_errors.o", "count_errors.hip", []),
-         ("channel.o", "channel.hip", [])]
-UNITS += [("decode_qc_r0.o", "decode_qc_r0.hip", []), ("decode_spec.o", "decode_spec.hip", []),
+# slowest units first: the pool starts them in this order
+UNITS = [(f"decode_spec_spaw_r{k}.o", "decode_spec_spaw.hip", [f"-DLDPC_SPAW_RULE={k}"]) for k in (2, 3, 4)]
+UNITS += [("decode_spec_spa.o", "decode_spec_spa.hip", []),
           ("decode_lnms.o", "decode_lnms.hip", []),
-          ("decode_qc_lnms.o", "decode_qc_lnms.hip", []),
-          ("decode_spec_spa.o", "decode_spec_spa.hip", []),
           ("decode_spec_r1w.o", "decode_spec_r1w.hip", []),
-          ("decode_spec_spaw.o", "decode_spec_spaw.hip", [])]
+          ("decode_spec.o", "decode_spec.hip", [])]
 UNITS += [(f"decode_qc_r{k}.o", "decode_qc.hip", [f"-DLDPC_QC_RULE={k}"]) for k in range(1, 5)]
+UNITS += [("decode_qc_r0.o", "decode_qc_r0.hip", []),
+          ("decode_qc_lnms.o", "decode_qc_lnms.hip", []),
+          ("decode_csr.o", "decode_csr.hip", []),
+          ("ldpc_abi.o", "ldpc_abi.hip", []),
+          ("count_errors.o", "count_errors.hip", []),
+          ("channel.o", "channel.hip", [])]
 HEADERS = ["bp_common.h", "bp_math.h", "spec_common.h", "spec_r1w_plan.h", os.path.join("gen", "codes_gen.h"),
            os.path.join(ROOT, "include", "ldpc_amd.h")]
 

@@ -79,9 +79,12 @@ hipError_t launch_spec_spa(int spec_id, const ldpc_decode_config &cfg, int compu
 // decode_spec_r1w.hip: rule R1 with several waves per frame group, for the larger packaged codes
 hipError_t launch_spec_r1w(int spec_id, const ldpc_decode_config &cfg, int compute_dtype, const Launch &io,
                            int num_cus, const char **kernel_name, bool *supported);
-// decode_spec_spaw.hip: rules R2-R4 with several waves per frame group
-hipError_t launch_spec_spaw(int spec_id, const ldpc_decode_config &cfg, int compute_dtype, const Launch &io,
-                            int num_cus, const char **kernel_name, bool *supported);
+// decode_spec_spaw.hip: rules R2-R4 with several waves per frame group, one translation unit per rule
+#define LDPC_DECL_SPAW(k)                                                                          \
+    hipError_t launch_spec_spaw_rule_##k(int spec_id, const ldpc_decode_config &cfg, int compute_dtype, \
+                                         const Launch &io, int num_cus, const char **kernel_name, bool *supported);
+LDPC_DECL_SPAW(2) LDPC_DECL_SPAW(3) LDPC_DECL_SPAW(4)
+#undef LDPC_DECL_SPAW
 // decode_qc_lnms.hip: the same rule for any circulant code, base graph in device tables
 hipError_t launch_qc_lnms(const QcDev &code, const ldpc_decode_config &cfg, int compute_dtype, const Launch &io,
                           int num_cus, void **workspace, size_t *workspace_bytes, const char **kernel_name,

@@ -486,7 +486,9 @@ hipError_t launch_spec(int spec_id, const ldpc_decode_config &cfg, int compute_d
     if (cfg.rule >= 2 && cfg.rule <= 4) {  // decode_spec_spa.hip, else decode_spec_spaw.hip
         hipError_t e = launch_spec_spa(spec_id, cfg, compute_dtype, io, num_cus, name, supported);
         if (e != hipSuccess || *supported) return e;
-        return launch_spec_spaw(spec_id, cfg, compute_dtype, io, num_cus, name, supported);
+        if (cfg.rule == 2) return launch_spec_spaw_rule_2(spec_id, cfg, compute_dtype, io, num_cus, name, supported);
+        if (cfg.rule == 3) return launch_spec_spaw_rule_3(spec_id, cfg, compute_dtype, io, num_cus, name, supported);
+        return launch_spec_spaw_rule_4(spec_id, cfg, compute_dtype, io, num_cus, name, supported);
     }
     if (cfg.rule == 0 || cfg.rule == 1) {  // decode_spec_r1w.hip: codes too large for one wave per workgroup
         hipError_t e = launch_spec_r1w(spec_id, cfg, compute_dtype, io, num_cus, name, supported);

@@ -291,16 +291,22 @@ static hipError_t launch_spaw_rule(const ldpc_decode_config &cfg, int compute_dt
     return hipSuccess;
 }
 
-hipError_t launch_spec_spaw(int spec_id, const ldpc_decode_config &cfg, int compute_dtype, const Launch &io,
-                            int num_cus, const char **name, bool *supported)
+// One translation unit per rule (-DLDPC_SPAW_RULE=2, 3, 4) so that the units compile side by side.
+#ifndef LDPC_SPAW_RULE
+#error "compile with -DLDPC_SPAW_RULE=2, 3 or 4"
+#endif
+#define LDPC_SPAW_CAT2(a, b) a##b
+#define LDPC_SPAW_CAT(a, b) LDPC_SPAW_CAT2(a, b)
+
+hipError_t LDPC_SPAW_CAT(launch_spec_spaw_rule_, LDPC_SPAW_RULE)(int spec_id, const ldpc_decode_config &cfg,
+                                                                 int compute_dtype, const Launch &io, int num_cus,
+                                                                 const char **name, bool *supported)
 {
     int id = 0;
 #define LDPC_LAUNCH(CODE, SLOTS)                                                                   \
     if (spec_id == id) {                                                                           \
         constexpr int F = SLOTS * CODE::Z <= 64 ? SLOTS : 1;                                       \
-        if (cfg.rule == 2) return launch_spaw_rule<2, CODE, F>(cfg, compute_dtype, io, num_cus, name, supported); \
-        if (cfg.rule == 3) return launch_spaw_rule<3, CODE, F>(cfg, compute_dtype, io, num_cus, name, supported); \
-        if (cfg.rule == 4) return launch_spaw_rule<4, CODE, F>(cfg, compute_dtype, io, num_cus, name, supported); \
+        return launch_spaw_rule<LDPC_SPAW_RULE, CODE, F>(cfg, compute_dtype, io, num_cus, name, supported); \
     }                                                                                              \
     ++id;
     LDPC_FOR_EACH_SPEC_CODE(LDPC_LAUNCH)
