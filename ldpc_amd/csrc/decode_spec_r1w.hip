@@ -466,19 +466,31 @@ static hipError_t launch_r0w(const ldpc_decode_config &cfg, const Launch &io, in
     return hipGetLastError();
 }
 
-// Rule R0 comes here only for base graphs the single-wave kernel does not unroll (more than 100 edges).
+// Rule R0 comes here for base graphs the single-wave kernel does not unroll (more than 100 edges)
+// and for codes whose single-wave footprint leaves fewer than eight workgroups per compute unit.
+template <class C, typename T, int F>
+constexpr bool r0w_wanted()
+{
+    constexpr int single = F * (C::NB * C::Z * (int)sizeof(T) + C::MB * C::Z * 2 * (int)sizeof(T));
+    return F * C::Z <= 64 && R0wLayout<C, T, F>::LDS_BYTES <= 160 * 1024 && C::EB <= 200 &&
+           (C::EB > 100 || (160 * 1024) / single < 8);
+}
+
 template <class C, int F>
 static hipError_t launch_r0w_code(const ldpc_decode_config &cfg, int compute_dtype, const Launch &io, int num_cus,
                                   const char **name, bool *supported)
 {
     *supported = true;
-    if constexpr (F * C::Z <= 64 && C::EB > 100 && C::EB <= 200 && R0wLayout<C, double, F>::LDS_BYTES <= 160 * 1024) {
-        constexpr int W = 4;
+    constexpr int W = 4;
+    if constexpr (r0w_wanted<C, double, F>()) {
         if (compute_dtype == LDPC_F64) {
             if (io.llr_dtype == LDPC_F64) return launch_r0w<C, double, double, F, W>(cfg, io, num_cus, name);
             return launch_r0w<C, double, float, F, W>(cfg, io, num_cus, name);
         }
-        if (io.llr_dtype == LDPC_F32) return launch_r0w<C, float, float, F, W>(cfg, io, num_cus, name);
+    }
+    if constexpr (r0w_wanted<C, float, F>()) {
+        if (compute_dtype == LDPC_F32 && io.llr_dtype == LDPC_F32)
+            return launch_r0w<C, float, float, F, W>(cfg, io, num_cus, name);
     }
     *supported = false;
     return hipSuccess;
