@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Turn the raw output of tools/profile_round.sh (gpurun_out/prof_<tag>/) into the summaries kept
+"""Turn the raw output of tools/profile_round.sh or tools/profile_bg2.sh (gpurun_out/prof_<tag>/) into the summaries kept
 under profiles/: the kernel-trace statistics of each bench workload (decoder kernels and the ten
 largest others) and the HBM traffic of the decode kernel from the FETCH_SIZE / WRITE_SIZE passes.
 
@@ -14,7 +14,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(ROOT, "profiles")
-WORKLOADS = {"ccsds_r0_f64": "ccsds512/R0/f64/f32llr", "bg1_lnms_f32": "nr_bg1_z384/LNMS/f32/f32llr"}
+WORKLOADS = {"ccsds_r0_f64": "ccsds512/R0/f64/f32llr", "bg1_lnms_f32": "nr_bg1_z384/LNMS/f32/f32llr",
+             "bg2_R0_f64": "nr_bg2_z40/R0/f64/f32llr", "bg2_R0_f32": "nr_bg2_z40/R0/f32/f32llr",
+             "bg2_R1_f32": "nr_bg2_z40/R1/f32/f32llr", "bg2_R3_f32": "nr_bg2_z40/R3/f32/f32llr"}
+# only the workloads this tag's run covered
+WORKLOADS = {wl: key for wl, key in WORKLOADS.items() if os.path.isdir(os.path.join(src, f"stats_{wl}"))}
 
 
 def decoder_kernel(name):
@@ -41,6 +45,8 @@ traffic = {"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate pa
                    "(128-byte requests tallied as 64), so the read side is doubled; WRITE_SIZE is taken as is.",
            "workloads": {}}
 for wl, key in WORKLOADS.items():
+    if not os.path.isdir(os.path.join(src, f"fetch_{wl}")):
+        continue
     vals = {}
     for ctr, d in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
         rows = list(csv.DictReader(open(os.path.join(src, f"{d}_{wl}", "t_counter_collection.csv"))))
