@@ -275,7 +275,8 @@ spec_r0w_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t 
             const bool float_check = t == 0 && g.float_syndrome0 && g.early_exit;  // ldpc.py:158,165
             // ---- check nodes of this wave's block rows (ldpc.py:175-187) and the syndrome
             unsigned bad = 0;
-            if (!done) {
+            auto check_phase = [&](auto float_chk) {  // the float test only exists at t == 0: its sums stay out of the loop's code
+                constexpr bool FC = decltype(float_chk)::value != 0;
                 static_for<0, W>([&](auto w) {
                     if (wave == w) {
                         static_for<0, MBW>([&](auto i) {
@@ -290,18 +291,22 @@ spec_r0w_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t 
                                     m2 = SNum<T>::second(m1, m2, b);
                                     m1 = SNum<T>::min_abs(m1, b);
                                     sx ^= SNum<T>::sign_word(b);
-                                    fsum += b;
+                                    if constexpr (FC) fsum += b;
                                 });
                                 if constexpr (D < 2) { m1 = (T)0; m2 = (T)0; }  // ldpc.py:178
                                 if (!last)
                                     *reinterpret_cast<Pair *>(cs_b + br * Z * SP + zp) =
                                         SNum<T>::make(SNum<T>::with_sign(m1, sx), SNum<T>::with_sign(m2, sx));
-                                if (float_check) bad |= !(t_fmod(fsum, (T)2) == (T)0);
+                                if constexpr (FC) bad |= !(t_fmod(fsum, (T)2) == (T)0);
                                 else bad |= ((unsigned)D ^ (sx >> 31)) & 1u;  // parity of the hard bits 1 - signbit
                             }
                         });
                     }
                 });
+            };
+            if (!done) {
+                if (float_check) check_phase(IC<1>{});
+                else check_phase(IC<0>{});
             }
             int *slot_bad = flags + (t & 1) * 8;
             if (bad && want_syn) slot_bad[f] = 1;
