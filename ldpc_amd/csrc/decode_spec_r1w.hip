@@ -32,19 +32,19 @@ struct R1wLayout {
 };
 
 template <class C, typename T, typename TL, int F, int W>
-__global__ void __launch_bounds__(64 * W)
+__global__ void __launch_bounds__(64 * W * ((F * C::Z + 63) / 64))
 spec_r1w_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__restrict__ hard_out,
                 int *__restrict__ iters_out, uint8_t *__restrict__ conv_out, T *__restrict__ post_out)
 {
     typedef R1wLayout<C, T, F> LY;
     typedef R1wPlan<C, W> PL;
     typedef typename SNum<T>::Pair Pair;
-    static_assert(LY::LANES <= 64, "a wave covers all slots");
+    constexpr int G = (LY::LANES + 63) / 64;  // lane groups: G waves side by side cover the F slots
     constexpr int Z = C::Z, NB = C::NB, MB = C::MB, ST = sizeof(T), SP = 2 * sizeof(T);
     constexpr int n = NB * Z, NBW = PL::NBW, QW = PL::QW, MBW = PL::MBW;
     extern __shared__ __align__(16) unsigned char smem[];
 
-    const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+    const int wave = ((int)threadIdx.x >> 6) / G, lane = (((int)threadIdx.x >> 6) % G) * 64 + ((int)threadIdx.x & 63);
     const bool lane_on = lane < F * Z;
     const int f = lane_on ? lane / Z : 0;
     const int z = lane_on ? lane - f * Z : 0;
@@ -223,19 +223,19 @@ struct R0wLayout {
 };
 
 template <class C, typename T, typename TL, int F, int W>
-__global__ void __launch_bounds__(64 * W)
+__global__ void __launch_bounds__(64 * W * ((F * C::Z + 63) / 64))
 spec_r0w_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__restrict__ hard_out,
                 int *__restrict__ iters_out, uint8_t *__restrict__ conv_out, T *__restrict__ post_out)
 {
     typedef R0wLayout<C, T, F> LY;
     typedef R1wPlan<C, W> PL;
     typedef typename SNum<T>::Pair Pair;
-    static_assert(LY::LANES <= 64, "a wave covers all slots");
+    constexpr int G = (LY::LANES + 63) / 64;  // lane groups: G waves side by side cover the F slots
     constexpr int Z = C::Z, NB = C::NB, ST = sizeof(T), SP = 2 * sizeof(T);
     constexpr int n = NB * Z, NBW = PL::NBW, MBW = PL::MBW;
     extern __shared__ __align__(16) unsigned char smem[];
 
-    const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+    const int wave = ((int)threadIdx.x >> 6) / G, lane = (((int)threadIdx.x >> 6) % G) * 64 + ((int)threadIdx.x & 63);
     const bool lane_on = lane < F * Z;
     const int f = lane_on ? lane / Z : 0;
     const int z = lane_on ? lane - f * Z : 0;
@@ -380,11 +380,26 @@ spec_r0w_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t 
     }
 }
 
+// Frame slots per workgroup: the code's slot count when those frames fit one wave; when they need
+// two waves side by side (Z = 40: three frames in 120 of 128 lanes instead of one in 40 of 64) only
+// if LDS holds them; else one frame.
+#ifndef LDPC_PACK_LDS
+#define LDPC_PACK_LDS (160 * 1024)
+#endif
+template <class C, typename T, int SLOTS, template <class, typename, int> class LAYOUT>
+constexpr int packed_slots()
+{
+    if (SLOTS * C::Z <= 64) return SLOTS;
+    if (SLOTS * C::Z <= 128 && LAYOUT<C, T, SLOTS>::LDS_BYTES <= LDPC_PACK_LDS) return SLOTS;
+    return 1;
+}
+
 // ------------------------------------------------------------------------------------------ host
 template <class C, typename T, typename TL, int F, int W>
 static hipError_t launch_r1w(const ldpc_decode_config &cfg, const Launch &io, int num_cus, const char **name)
 {
     typedef R1wLayout<C, T, F> LY;
+    constexpr int G = (LY::LANES + 63) / 64;
     Cfg<T> g;
     g.rule = 1; g.max_iters = cfg.max_iters; g.early_exit = cfg.early_exit;
     g.float_syndrome0 = 0; g.num_active_checks = -1; g.num_refresh_vars = -1;
@@ -394,14 +409,14 @@ static hipError_t launch_r1w(const ldpc_decode_config &cfg, const Launch &io, in
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LY::LDS_BYTES);
     if (e != hipSuccess) return e;
     int per_cu = 0;
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k), 64 * W, LY::LDS_BYTES);
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k), 64 * W * G, LY::LDS_BYTES);
     if (e != hipSuccess) return e;
     if (per_cu < 1) per_cu = 1;
     const long long groups = (io.frames + F - 1) / F;
     long long grid = (long long)num_cus * per_cu * 2;
     if (grid > groups) grid = groups;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(64 * W), LY::LDS_BYTES, io.stream, g,
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(64 * W * G), LY::LDS_BYTES, io.stream, g,
                        reinterpret_cast<const TL *>(io.llr), io.frames, io.hard, io.iters, io.converged,
                        reinterpret_cast<T *>(io.posterior));
     *name = sizeof(T) == 8 ? "spec_r1w_f64" : "spec_r1w_f32";
@@ -415,7 +430,7 @@ template <class C, typename T, int F>
 constexpr bool r1w_wanted()
 {
     constexpr int single = F * (C::EB * C::Z * (int)sizeof(T) + C::MB * C::Z * 2 * (int)sizeof(T));
-    return F * C::Z <= 64 && R1wLayout<C, T, F>::LDS_BYTES <= 160 * 1024 && C::EB <= 200 &&
+    return F * C::Z <= 128 && R1wLayout<C, T, F>::LDS_BYTES <= 160 * 1024 && C::EB <= 200 &&
            (C::EB > 100 || (160 * 1024) / single < 8);
 }
 
@@ -423,22 +438,23 @@ constexpr bool r1w_wanted()
 template <class C, typename T, int F>
 constexpr int r1w_waves() { return R1wLayout<C, T, F>::LDS_BYTES > 80 * 1024 ? 8 : 4; }
 
-template <class C, int F>
+template <class C, int SLOTS>
 static hipError_t launch_r1w_code(const ldpc_decode_config &cfg, int compute_dtype, const Launch &io, int num_cus,
                                   const char **name, bool *supported)
 {
     *supported = true;
-    if constexpr (r1w_wanted<C, double, F>()) {
-        constexpr int W = r1w_waves<C, double, F>();
+    constexpr int FD = packed_slots<C, double, SLOTS, R1wLayout>(), FF = packed_slots<C, float, SLOTS, R1wLayout>();
+    if constexpr (r1w_wanted<C, double, FD>()) {
+        constexpr int W = r1w_waves<C, double, FD>();
         if (compute_dtype == LDPC_F64) {
-            if (io.llr_dtype == LDPC_F64) return launch_r1w<C, double, double, F, W>(cfg, io, num_cus, name);
-            return launch_r1w<C, double, float, F, W>(cfg, io, num_cus, name);
+            if (io.llr_dtype == LDPC_F64) return launch_r1w<C, double, double, FD, W>(cfg, io, num_cus, name);
+            return launch_r1w<C, double, float, FD, W>(cfg, io, num_cus, name);
         }
     }
-    if constexpr (r1w_wanted<C, float, F>()) {
-        constexpr int W = r1w_waves<C, float, F>();
+    if constexpr (r1w_wanted<C, float, FF>()) {
+        constexpr int W = r1w_waves<C, float, FF>();
         if (compute_dtype == LDPC_F32 && io.llr_dtype == LDPC_F32)
-            return launch_r1w<C, float, float, F, W>(cfg, io, num_cus, name);
+            return launch_r1w<C, float, float, FF, W>(cfg, io, num_cus, name);
     }
     *supported = false;
     return hipSuccess;
@@ -448,6 +464,7 @@ template <class C, typename T, typename TL, int F, int W>
 static hipError_t launch_r0w(const ldpc_decode_config &cfg, const Launch &io, int num_cus, const char **name)
 {
     typedef R0wLayout<C, T, F> LY;
+    constexpr int G = (LY::LANES + 63) / 64;
     Cfg<T> g;
     g.rule = 0; g.max_iters = cfg.max_iters; g.early_exit = cfg.early_exit;
     g.float_syndrome0 = cfg.float_syndrome0; g.num_active_checks = -1; g.num_refresh_vars = -1;
@@ -457,14 +474,14 @@ static hipError_t launch_r0w(const ldpc_decode_config &cfg, const Launch &io, in
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LY::LDS_BYTES);
     if (e != hipSuccess) return e;
     int per_cu = 0;
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k), 64 * W, LY::LDS_BYTES);
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k), 64 * W * G, LY::LDS_BYTES);
     if (e != hipSuccess) return e;
     if (per_cu < 1) per_cu = 1;
     const long long groups = (io.frames + F - 1) / F;
     long long grid = (long long)num_cus * per_cu * 2;
     if (grid > groups) grid = groups;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(64 * W), LY::LDS_BYTES, io.stream, g,
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(64 * W * G), LY::LDS_BYTES, io.stream, g,
                        reinterpret_cast<const TL *>(io.llr), io.frames, io.hard, io.iters, io.converged,
                        reinterpret_cast<T *>(io.posterior));
     *name = sizeof(T) == 8 ? "spec_r0w_f64" : "spec_r0w_f32";
@@ -477,25 +494,26 @@ template <class C, typename T, int F>
 constexpr bool r0w_wanted()
 {
     constexpr int single = F * (C::NB * C::Z * (int)sizeof(T) + C::MB * C::Z * 2 * (int)sizeof(T));
-    return F * C::Z <= 64 && R0wLayout<C, T, F>::LDS_BYTES <= 160 * 1024 && C::EB <= 200 &&
+    return F * C::Z <= 128 && R0wLayout<C, T, F>::LDS_BYTES <= 160 * 1024 && C::EB <= 200 &&
            (C::EB > 100 || (160 * 1024) / single < 8);
 }
 
-template <class C, int F>
+template <class C, int SLOTS>
 static hipError_t launch_r0w_code(const ldpc_decode_config &cfg, int compute_dtype, const Launch &io, int num_cus,
                                   const char **name, bool *supported)
 {
     *supported = true;
     constexpr int W = 4;
-    if constexpr (r0w_wanted<C, double, F>()) {
+    constexpr int FD = packed_slots<C, double, SLOTS, R0wLayout>(), FF = packed_slots<C, float, SLOTS, R0wLayout>();
+    if constexpr (r0w_wanted<C, double, FD>()) {
         if (compute_dtype == LDPC_F64) {
-            if (io.llr_dtype == LDPC_F64) return launch_r0w<C, double, double, F, W>(cfg, io, num_cus, name);
-            return launch_r0w<C, double, float, F, W>(cfg, io, num_cus, name);
+            if (io.llr_dtype == LDPC_F64) return launch_r0w<C, double, double, FD, W>(cfg, io, num_cus, name);
+            return launch_r0w<C, double, float, FD, W>(cfg, io, num_cus, name);
         }
     }
-    if constexpr (r0w_wanted<C, float, F>()) {
+    if constexpr (r0w_wanted<C, float, FF>()) {
         if (compute_dtype == LDPC_F32 && io.llr_dtype == LDPC_F32)
-            return launch_r0w<C, float, float, F, W>(cfg, io, num_cus, name);
+            return launch_r0w<C, float, float, FF, W>(cfg, io, num_cus, name);
     }
     *supported = false;
     return hipSuccess;
@@ -507,9 +525,8 @@ hipError_t launch_spec_r1w(int spec_id, const ldpc_decode_config &cfg, int compu
     int id = 0;
 #define LDPC_LAUNCH(CODE, SLOTS)                                                                   \
     if (spec_id == id) {                                                                           \
-        constexpr int F = SLOTS * CODE::Z <= 64 ? SLOTS : 1;                                       \
-        if (cfg.rule == 0) return launch_r0w_code<CODE, F>(cfg, compute_dtype, io, num_cus, name, supported); \
-        return launch_r1w_code<CODE, F>(cfg, compute_dtype, io, num_cus, name, supported);         \
+        if (cfg.rule == 0) return launch_r0w_code<CODE, SLOTS>(cfg, compute_dtype, io, num_cus, name, supported); \
+        return launch_r1w_code<CODE, SLOTS>(cfg, compute_dtype, io, num_cus, name, supported);     \
     }                                                                                              \
     ++id;
     LDPC_FOR_EACH_SPEC_CODE(LDPC_LAUNCH)
