@@ -218,6 +218,17 @@ lnms_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__r
     const unsigned stW = (unsigned)f * LY::SLOT_BYTES + 2 * Z * ST + (unsigned)z * 4;
     int *slot_bad = reinterpret_cast<int *>(smem + LY::FLAG_OFF);
     const unsigned long long slot_mask = (Z >= 64 ? ~0ull : ((1ull << (Z & 63)) - 1ull)) << ((f * Z) & 63);
+    // lanes of this wave that work on the same slot as this lane
+    unsigned long long wave_slot_mask = slot_mask;
+    if constexpr (!LY::SINGLE && F > 1) {
+        static_for<0, F>([&](auto ff) {
+            const unsigned long long m = __ballot(lane_on && f == ff);
+            if (f == ff) wave_slot_mask = m;
+        });
+    } else if constexpr (!LY::SINGLE) {
+        wave_slot_mask = ~0ull;
+    }
+    volatile int *slot_bad_now = slot_bad;  // polled while other waves may still be writing
 
     const long long groups = (frames + F - 1) / F;
     for (long long grp = blockIdx.x; grp < groups; grp += gridDim.x) {
@@ -349,6 +360,7 @@ lnms_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__r
         // (cyclically over the sweeps, hence a divisor of the number of such layers).  One layer
         // ahead measured fastest: deeper queues cost registers the layers need themselves.
         constexpr int NPL = PL::n_priv_layers();
+        constexpr int SYN_FIRST = 2, SYN_EVERY = 6;  // block rows between looks at the outcome of the syndrome test
 #ifndef LDPC_LNMS_PFS
 #define LDPC_LNMS_PFS 1
 #endif
@@ -366,9 +378,21 @@ lnms_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__r
                 // ---- syndrome of the hard decisions `0 if P > 0 else 1` of the current posteriors
                 if constexpr (!LY::SINGLE) __syncthreads();
                 if (last && g.early_exit) break;  // no test after the last sweep
+                // A failed test needs no more rows: every few block rows a wave stops if each of its
+                // slots is known to have failed, from its own lanes or from the flag another wave set.
                 unsigned bad = 0;
-                if (!done) {
+                bool skip = false;  // the same in all lanes of a wave
+                if (!done || !LY::SINGLE) {
                     static_for<0, MB>([&](auto br) {
+                        if constexpr (br == SYN_FIRST || (br > SYN_FIRST && (br - SYN_FIRST) % SYN_EVERY == 0)) {
+                            bool known = done || (__ballot(bad != 0) & wave_slot_mask) != 0ull;
+                            if constexpr (!LY::SINGLE) {
+                                if (bad) slot_bad_now[f] = 1;
+                                known = known || slot_bad_now[f] != 0;
+                            }
+                            skip = __ballot(!known) == 0ull;
+                        }
+                        if (skip || done) return;
                         constexpr int e0 = C::row_ptr[br], D = C::row_ptr[br + 1] - e0, PP = PL::priv_pos(br);
                         unsigned zl = zb;
                         asm volatile("" : "+v"(zl));  // keep the rotated addresses out of loop-invariant hoisting
