@@ -207,6 +207,205 @@ spec_r1w_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t 
     }
 }
 
+// ------------------------------------------------------------------------------ R1, independent slots
+// Early-exit decoding with several slots per workgroup: frames need very different numbers of
+// iterations (one to thirty), and a workgroup that starts its slots together waits for the slowest.
+// Here every slot runs its own queue of frames - slot s of workgroup b decodes frames
+// (b + k * gridDim.x) * F + s, k = 0, 1, ... - and moves on to its next frame the moment the current
+// one ends, while the other slots carry on; the slots only share the two barriers per iteration.
+// Every wave tracks all slots' iteration counters and queue positions as uniform values (they
+// follow from the syndrome flags every wave reads), so the loop ends for all waves together when
+// the last queue is empty.  Same arithmetic as spec_r1w_kernel; g.early_exit != 0, max_iters >= 1.
+template <class C, typename T, typename TL, int F, int W>
+__global__ void __launch_bounds__(64 * W * ((F * C::Z + 63) / 64))
+spec_r1w_slots_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__restrict__ hard_out,
+                      int *__restrict__ iters_out, uint8_t *__restrict__ conv_out, T *__restrict__ post_out)
+{
+    typedef R1wLayout<C, T, F> LY;
+    typedef R1wPlan<C, W> PL;
+    typedef typename SNum<T>::Pair Pair;
+    constexpr int G = (LY::LANES + 63) / 64;
+    constexpr int Z = C::Z, NB = C::NB, ST = sizeof(T), SP = 2 * sizeof(T);
+    constexpr int n = NB * Z, NBW = PL::NBW, QW = PL::QW, MBW = PL::MBW;
+    extern __shared__ __align__(16) unsigned char smem[];
+
+    const int wave = ((int)threadIdx.x >> 6) / G, lane = (((int)threadIdx.x >> 6) % G) * 64 + ((int)threadIdx.x & 63);
+    const bool lane_on = lane < F * Z;
+    const int f = lane_on ? lane / Z : 0;
+    const int z = lane_on ? lane - f * Z : 0;
+    unsigned char *qv_b = smem + f * LY::SLOT_BYTES;
+    unsigned char *cs_b = qv_b + LY::QV_BYTES;
+    unsigned char *hb_b = cs_b + LY::CS_BYTES;
+    int *flags = reinterpret_cast<int *>(smem + LY::FLAG_OFF);
+    const unsigned zb = (unsigned)z * ST, zp = (unsigned)z * SP, z1 = (unsigned)z;
+
+    const long long stride = (long long)gridDim.x * F;
+    // uniform view of every slot: current frame and iteration
+    long long frame_s[F];
+    int t_s[F];
+    static_for<0, F>([&](auto ff) { frame_s[ff] = (long long)blockIdx.x * F + ff; t_s[ff] = 0; });
+    // this lane's slot
+    long long frame = (long long)blockIdx.x * F + f;
+    int t = 0;
+    bool live = lane_on && frame < frames;
+
+    T L[NBW], own[NBW], q[QW];
+    // every edge of the slot's new frame carries the channel LLR (bpsk.py:170-177)
+    auto load_frame = [&]() {
+        static_for<0, W>([&](auto w) {
+            if (wave == w) {
+                static_for<0, NBW>([&](auto j) {
+                    if constexpr (j < PL::COLS.cnt[w]) {
+                        constexpr int bc = PL::COLS.item[w][j];
+                        constexpr int k0 = C::col_ptr[bc], D = C::col_ptr[bc + 1] - k0, q0 = PL::COLS.edge0[w][j];
+                        const T l = (T)llr[frame * n + bc * Z + z];
+                        L[j] = l;
+                        own[j] = l;
+                        hb_b[bc * Z + z1] = (uint8_t)hard_bit<1>(l);
+                        static_for<0, D>([&](auto k) {
+                            q[q0 + k] = l;
+                            *reinterpret_cast<T *>(qv_b + (k0 + k) * Z * ST + zb) = l;
+                        });
+                    }
+                });
+            }
+        });
+    };
+    static_for<0, NBW>([&](auto j) { L[j] = (T)0; own[j] = (T)0; });
+    static_for<0, QW>([&](auto k) { q[k] = (T)0; });
+    if (live) load_frame();
+    if (threadIdx.x < 16) flags[threadIdx.x] = 0;
+    __syncthreads();
+
+    for (int round = 0;; ++round) {
+        bool any_live = false;
+        static_for<0, F>([&](auto ff) { any_live |= frame_s[ff] < frames; });
+        if (!any_live) break;  // uniform: every queue is empty
+        // ---- check nodes of this wave's block rows and the parity of the current hard decisions
+        unsigned bad = 0;
+        if (live) {
+            static_for<0, W>([&](auto w) {
+                if (wave == w) {
+                    static_for<0, MBW>([&](auto i) {
+                        if constexpr (i < PL::ROWS.cnt[w]) {
+                            constexpr int br = PL::ROWS.item[w][i];
+                            constexpr int e0 = C::row_ptr[br], D = C::row_ptr[br + 1] - e0;
+                            T m1 = Lim<T>::inf(), m2 = Lim<T>::inf();
+                            unsigned sx = 0, par = 0;
+                            static_for<0, D>([&](auto p) {
+                                constexpr int kpos = C::row_kpos[e0 + p], s = C::row_shift[e0 + p], bc = C::row_col[e0 + p];
+                                const T v = *reinterpret_cast<const T *>(qv_b + kpos * Z * ST + rot_fwd<Z, ST, s>(zb));
+                                par ^= hb_b[bc * Z + rot_fwd<Z, 1, s>(z1)];
+                                m2 = SNum<T>::second(m1, m2, v);
+                                m1 = SNum<T>::min_abs(m1, v);
+                                sx ^= SNum<T>::sign_word(v);
+                            });
+                            if constexpr (D < 2) { m1 = (T)0; m2 = (T)0; }  // bpsk.py:216
+                            *reinterpret_cast<Pair *>(cs_b + br * Z * SP + zp) =
+                                SNum<T>::make(SNum<T>::with_sign(m1, sx), SNum<T>::with_sign(m2, sx));
+                            bad |= par;
+                        }
+                    });
+                }
+            });
+        }
+        int *slot_bad = flags + (round & 1) * 8;
+        if (bad) slot_bad[f] = 1;
+        __syncthreads();
+        if (threadIdx.x < 8) flags[((round + 1) & 1) * 8 + threadIdx.x] = 0;
+        // ---- outcome per slot, the same in every wave
+        bool ok_s[F];
+        static_for<0, F>([&](auto ff) { ok_s[ff] = __builtin_amdgcn_readfirstlane(slot_bad[ff]) == 0; });
+        bool slot_ok = ok_s[0];
+        static_for<1, F>([&](auto ff) { if (f == ff) slot_ok = ok_s[ff]; });
+        const bool converged = live && slot_ok;   // bpsk.py:205-209
+        const bool update = live && !slot_ok;
+        // ---- variable nodes of this wave's block columns (bpsk.py:235-247)
+        if (update) {
+            static_for<0, W>([&](auto w) {
+                if (wave == w) {
+                    static_for<0, NBW>([&](auto j) {
+                        if constexpr (j < PL::COLS.cnt[w]) {
+                            constexpr int bc = PL::COLS.item[w][j];
+                            constexpr int k0 = C::col_ptr[bc], D = C::col_ptr[bc + 1] - k0, q0 = PL::COLS.edge0[w][j];
+                            T r[D > 0 ? D : 1], qn[D > 0 ? D : 1];
+                            unsigned off[D > 0 ? D : 1];
+                            static_for<0, D>([&](auto k) {
+                                constexpr int br = C::col_row[k0 + k], s = C::col_shift[k0 + k];
+                                const T qo = q[q0 + k];
+                                off[k] = rot_bwd<Z, SP, s>(zp);
+                                const Pair c = *reinterpret_cast<const Pair *>(cs_b + br * Z * SP + off[k]);
+                                const T sel = t_abs(qo) == t_abs(c.x) ? c.y : c.x;
+                                r[k] = SNum<T>::flip_sign(g.scale * sel, SNum<T>::sign_word(qo) & 0x80000000u);
+                            });
+                            bool sw[D > 0 ? D : 1];
+                            static_for<0, (D > 0 ? D - 1 : 0)>([&](auto k) {
+                                if constexpr (C::col_pair[k0 + k] != 0) {  // lower check index first
+                                    sw[k] = off[k] > off[k + 1];
+                                    const T a = r[k], b = r[k + 1];
+                                    r[k] = sw[k] ? b : a;
+                                    r[k + 1] = sw[k] ? a : b;
+                                }
+                            });
+                            T run = (T)0;
+                            static_for<0, D>([&](auto k) {
+                                T ext = run;
+                                static_for<k + 1, D>([&](auto kk) { ext += r[kk]; });
+                                run += r[k];
+                                qn[k] = L[j] + ext;
+                            });
+                            static_for<0, (D > 0 ? D - 1 : 0)>([&](auto k) {
+                                if constexpr (C::col_pair[k0 + k] != 0) {
+                                    const T a = qn[k], b = qn[k + 1];
+                                    qn[k] = sw[k] ? b : a;
+                                    qn[k + 1] = sw[k] ? a : b;
+                                }
+                            });
+                            static_for<0, D>([&](auto k) {
+                                q[q0 + k] = qn[k];
+                                *reinterpret_cast<T *>(qv_b + (k0 + k) * Z * ST + zb) = qn[k];
+                            });
+                            own[j] = L[j] + run;  // bpsk.py:237
+                            hb_b[bc * Z + z1] = (uint8_t)hard_bit<1>(own[j]);
+                        }
+                    });
+                }
+            });
+        }
+        // ---- a frame ends with a zero syndrome, or after its last update without a further test
+        //      (bpsk.py:200-248); both ways numIterations is the current counter
+        const bool ends = converged || (update && t == g.max_iters - 1);
+        if (ends) {
+            static_for<0, W>([&](auto w) {
+                if (wave == w) {
+                    static_for<0, NBW>([&](auto j) {
+                        if constexpr (j < PL::COLS.cnt[w]) {
+                            constexpr int bc = PL::COLS.item[w][j];
+                            hard_out[frame * n + bc * Z + z] = (uint8_t)hard_bit<1>(own[j]);
+                            if (post_out) post_out[frame * n + bc * Z + z] = own[j];
+                        }
+                    });
+                }
+            });
+            if (wave == 0 && z == 0) { iters_out[frame] = t; conv_out[frame] = (uint8_t)converged; }
+            frame += stride;
+            t = 0;
+            live = frame < frames;
+            if (live) load_frame();
+        } else if (update) {
+            ++t;
+        }
+        // the uniform copies take the same steps
+        static_for<0, F>([&](auto ff) {
+            if (frame_s[ff] < frames) {
+                if (ok_s[ff] || t_s[ff] == g.max_iters - 1) { frame_s[ff] += stride; t_s[ff] = 0; }
+                else ++t_s[ff];
+            }
+        });
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------------------ R0
 // Rule R0 (ldpc.py:137-227) with the same division of work.  Its variable-to-check message is the
 // posterior itself (ldpc.py:180-187 reads bitNodes), so LDS per slot only holds
@@ -405,6 +604,9 @@ static hipError_t launch_r1w(const ldpc_decode_config &cfg, const Launch &io, in
     g.float_syndrome0 = 0; g.num_active_checks = -1; g.num_refresh_vars = -1;
     g.scale = (T)cfg.scale; g.clip_tanh_arg = (T)0; g.clip_prod = (T)0; g.clip_post = (T)0;
     auto k = spec_r1w_kernel<C, T, TL, F, W>;
+    if constexpr (F > 1) {  // early exit with several slots: every slot runs its own queue of frames
+        if (cfg.early_exit && cfg.max_iters >= 1) k = spec_r1w_slots_kernel<C, T, TL, F, W>;
+    }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LY::LDS_BYTES);
     if (e != hipSuccess) return e;
