@@ -28,7 +28,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 UNITS = [(f"decode_spec_spaw_r{k}.o", "decode_spec_spaw.hip", [f"-DLDPC_SPAW_RULE={k}"]) for k in (2, 3, 4)]
 UNITS += [("decode_spec_spa.o", "decode_spec_spa.hip", []),
           ("decode_lnms.o", "decode_lnms.hip", []),
-          ("decode_spec_r1w.o", "decode_spec_r1w.hip", []),
+          ("decode_spec_r1w_r1.o", "decode_spec_r1w.hip", ["-DLDPC_R1W_RULE=1"]),
+          ("decode_spec_r1w_r0.o", "decode_spec_r1w.hip", ["-DLDPC_R1W_RULE=0"]),
           ("decode_spec.o", "decode_spec.hip", [])]
 UNITS += [(f"decode_qc_r{k}.o", "decode_qc.hip", [f"-DLDPC_QC_RULE={k}"]) for k in range(1, 5)]
 UNITS += [("decode_qc_r0.o", "decode_qc_r0.hip", []),

@@ -76,7 +76,10 @@ hipError_t launch_spec_lnms(int spec_id, const ldpc_decode_config &cfg, int comp
 // decode_spec_spa.hip: sum-product rules R2-R4, specialised for the small packaged codes
 hipError_t launch_spec_spa(int spec_id, const ldpc_decode_config &cfg, int compute_dtype, const Launch &io,
                            int num_cus, const char **kernel_name, bool *supported);
-// decode_spec_r1w.hip: rule R1 with several waves per frame group, for the larger packaged codes
+// decode_spec_r1w.hip: rules R0 and R1 with several waves per frame group, for the larger packaged
+// codes; one translation unit per rule
+hipError_t launch_spec_r0w(int spec_id, const ldpc_decode_config &cfg, int compute_dtype, const Launch &io,
+                           int num_cus, const char **kernel_name, bool *supported);
 hipError_t launch_spec_r1w(int spec_id, const ldpc_decode_config &cfg, int compute_dtype, const Launch &io,
                            int num_cus, const char **kernel_name, bool *supported);
 // decode_spec_spaw.hip: rules R2-R4 with several waves per frame group, one translation unit per rule

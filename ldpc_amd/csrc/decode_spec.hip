@@ -491,7 +491,8 @@ hipError_t launch_spec(int spec_id, const ldpc_decode_config &cfg, int compute_d
         return launch_spec_spaw_rule_4(spec_id, cfg, compute_dtype, io, num_cus, name, supported);
     }
     if (cfg.rule == 0 || cfg.rule == 1) {  // decode_spec_r1w.hip: codes too large for one wave per workgroup
-        hipError_t e = launch_spec_r1w(spec_id, cfg, compute_dtype, io, num_cus, name, supported);
+        hipError_t e = cfg.rule == 0 ? launch_spec_r0w(spec_id, cfg, compute_dtype, io, num_cus, name, supported)
+                                     : launch_spec_r1w(spec_id, cfg, compute_dtype, io, num_cus, name, supported);
         if (e != hipSuccess || *supported) return e;
     }
     int id = 0;

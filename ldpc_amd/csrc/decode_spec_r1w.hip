@@ -721,16 +721,29 @@ static hipError_t launch_r0w_code(const ldpc_decode_config &cfg, int compute_dty
     return hipSuccess;
 }
 
+// One translation unit per rule (-DLDPC_R1W_RULE=0 or 1) so that the two compile side by side;
+// templates the unit does not launch are never instantiated.
+#ifndef LDPC_R1W_RULE
+#error "compile with -DLDPC_R1W_RULE=0 or 1"
+#endif
+#if LDPC_R1W_RULE == 0
+hipError_t launch_spec_r0w(int spec_id, const ldpc_decode_config &cfg, int compute_dtype, const Launch &io,
+                           int num_cus, const char **name, bool *supported)
+#else
 hipError_t launch_spec_r1w(int spec_id, const ldpc_decode_config &cfg, int compute_dtype, const Launch &io,
                            int num_cus, const char **name, bool *supported)
+#endif
 {
     int id = 0;
+#if LDPC_R1W_RULE == 0
 #define LDPC_LAUNCH(CODE, SLOTS)                                                                   \
-    if (spec_id == id) {                                                                           \
-        if (cfg.rule == 0) return launch_r0w_code<CODE, SLOTS>(cfg, compute_dtype, io, num_cus, name, supported); \
-        return launch_r1w_code<CODE, SLOTS>(cfg, compute_dtype, io, num_cus, name, supported);     \
-    }                                                                                              \
+    if (spec_id == id) return launch_r0w_code<CODE, SLOTS>(cfg, compute_dtype, io, num_cus, name, supported); \
     ++id;
+#else
+#define LDPC_LAUNCH(CODE, SLOTS)                                                                   \
+    if (spec_id == id) return launch_r1w_code<CODE, SLOTS>(cfg, compute_dtype, io, num_cus, name, supported); \
+    ++id;
+#endif
     LDPC_FOR_EACH_SPEC_CODE(LDPC_LAUNCH)
 #undef LDPC_LAUNCH
     *supported = false;
