@@ -632,7 +632,7 @@ template <class C, typename T, int F>
 constexpr bool r1w_wanted()
 {
     constexpr int single = F * (C::EB * C::Z * (int)sizeof(T) + C::MB * C::Z * 2 * (int)sizeof(T));
-    return F * C::Z <= 128 && R1wLayout<C, T, F>::LDS_BYTES <= 160 * 1024 && C::EB <= 200 &&
+    return C::Z <= 64 && F * C::Z <= 128 && R1wLayout<C, T, F>::LDS_BYTES <= 160 * 1024 && C::EB <= 200 &&
            (C::EB > 100 || (160 * 1024) / single < 8);
 }
 
@@ -696,7 +696,7 @@ template <class C, typename T, int F>
 constexpr bool r0w_wanted()
 {
     constexpr int single = F * (C::NB * C::Z * (int)sizeof(T) + C::MB * C::Z * 2 * (int)sizeof(T));
-    return F * C::Z <= 128 && R0wLayout<C, T, F>::LDS_BYTES <= 160 * 1024 && C::EB <= 200 &&
+    return C::Z <= 64 && F * C::Z <= 128 && R0wLayout<C, T, F>::LDS_BYTES <= 160 * 1024 && C::EB <= 200 &&
            (C::EB > 100 || (160 * 1024) / single < 8);
 }
 
