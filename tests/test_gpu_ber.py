@@ -1,5 +1,5 @@
-"""Error-rate curves against the reference's own Monte-Carlo run (the
-reference ldpc.py decoder on CCSDS (512,256), 200 random codewords per point, Es/N0 0..4 dB).
+"""Error-rate curves against the reference's own Monte-Carlo run (the reference's ldpc.py decoder
+run on CCSDS (512,256) with 200 random codewords per point, Es/N0 0..4 dB; counts below).
 The GPU sweep uses far more frames; its frame-error rate must lie inside the Clopper-Pearson
 interval of the reference's counts, and float32 must tell the same story as float64."""
 import numpy as np
