@@ -27,18 +27,18 @@ struct SpawLayout {
 };
 
 template <int RULE, class C, typename T, typename TL, int F, int W>
-__global__ void __launch_bounds__(64 * W)
+__global__ void __launch_bounds__(64 * W * ((F * C::Z + 63) / 64))
 spec_spaw_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__restrict__ hard_out,
                  int *__restrict__ iters_out, uint8_t *__restrict__ conv_out, T *__restrict__ post_out)
 {
     typedef SpawLayout<C, T, F> LY;
     typedef R1wPlan<C, W> PL;
-    static_assert(LY::LANES <= 64, "a wave covers all slots");
+    constexpr int G = (LY::LANES + 63) / 64;  // lane groups: G waves side by side cover the F slots
     constexpr int Z = C::Z, NB = C::NB, ST = sizeof(T);
     constexpr int n = NB * Z, NBW = PL::NBW, MBW = PL::MBW;
     extern __shared__ __align__(16) unsigned char smem[];
 
-    const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+    const int wave = ((int)threadIdx.x >> 6) / G, lane = (((int)threadIdx.x >> 6) % G) * 64 + ((int)threadIdx.x & 63);
     const bool lane_on = lane < F * Z;
     const int f = lane_on ? lane / Z : 0;
     const int z = lane_on ? lane - f * Z : 0;
@@ -234,6 +234,7 @@ template <int RULE, class C, typename T, typename TL, int F, int W>
 static hipError_t launch_spaw(const ldpc_decode_config &cfg, const Launch &io, int num_cus, const char **name)
 {
     typedef SpawLayout<C, T, F> LY;
+    constexpr int G = (LY::LANES + 63) / 64;
     Cfg<T> g;
     g.rule = RULE; g.max_iters = cfg.max_iters; g.early_exit = cfg.early_exit;
     g.float_syndrome0 = 0; g.num_active_checks = -1; g.num_refresh_vars = -1;
@@ -244,14 +245,14 @@ static hipError_t launch_spaw(const ldpc_decode_config &cfg, const Launch &io, i
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LY::LDS_BYTES);
     if (e != hipSuccess) return e;
     int per_cu = 0;
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k), 64 * W, LY::LDS_BYTES);
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k), 64 * W * G, LY::LDS_BYTES);
     if (e != hipSuccess) return e;
     if (per_cu < 1) per_cu = 1;
     const long long groups = (io.frames + F - 1) / F;
     long long grid = (long long)num_cus * per_cu * 2;
     if (grid > groups) grid = groups;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(64 * W), LY::LDS_BYTES, io.stream, g,
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(64 * W * G), LY::LDS_BYTES, io.stream, g,
                        reinterpret_cast<const TL *>(io.llr), io.frames, io.hard, io.iters, io.converged,
                        reinterpret_cast<T *>(io.posterior));
     *name = sizeof(T) == 8 ? "spec_spaw_f64" : "spec_spaw_f32";
@@ -263,29 +264,44 @@ template <class C, typename T, int F>
 constexpr bool spaw_wanted()
 {
     constexpr int single = F * C::EB * C::Z * (int)sizeof(T);
-    return F * C::Z <= 64 && SpawLayout<C, T, F>::LDS_BYTES <= 160 * 1024 && C::EB <= 200 &&
+    return C::Z <= 64 && F * C::Z <= 128 && SpawLayout<C, T, F>::LDS_BYTES <= 160 * 1024 && C::EB <= 200 &&
            (C::EB > 100 || (160 * 1024) / single < 8);
 }
 
 #ifndef LDPC_SPAW_WAVES
 #define LDPC_SPAW_WAVES 4
 #endif
+#ifndef LDPC_SPAW_WAVES_PACKED
+#define LDPC_SPAW_WAVES_PACKED 8  // per lane group, when a workgroup carries two lane groups
+#endif
 
-template <int RULE, class C, int F>
+// Frame slots per workgroup: as in decode_spec_r1w.hip (three Z = 40 frames over two lane groups
+// where LDS holds them).
+template <class C, typename T, int SLOTS>
+constexpr int spaw_slots()
+{
+    if (SLOTS * C::Z <= 64) return SLOTS;
+    if (SLOTS * C::Z <= 128 && SpawLayout<C, T, SLOTS>::LDS_BYTES <= 160 * 1024) return SLOTS;
+    return 1;
+}
+
+template <int RULE, class C, int SLOTS>
 static hipError_t launch_spaw_rule(const ldpc_decode_config &cfg, int compute_dtype, const Launch &io, int num_cus,
                                    const char **name, bool *supported)
 {
-    constexpr int W = LDPC_SPAW_WAVES;
+    constexpr int FD = spaw_slots<C, double, SLOTS>(), FF = spaw_slots<C, float, SLOTS>();
     *supported = true;
-    if constexpr (spaw_wanted<C, double, F>()) {
+    if constexpr (spaw_wanted<C, double, FD>()) {
+        constexpr int W = FD * C::Z > 64 ? LDPC_SPAW_WAVES_PACKED : LDPC_SPAW_WAVES;
         if (compute_dtype == LDPC_F64) {
-            if (io.llr_dtype == LDPC_F64) return launch_spaw<RULE, C, double, double, F, W>(cfg, io, num_cus, name);
-            return launch_spaw<RULE, C, double, float, F, W>(cfg, io, num_cus, name);
+            if (io.llr_dtype == LDPC_F64) return launch_spaw<RULE, C, double, double, FD, W>(cfg, io, num_cus, name);
+            return launch_spaw<RULE, C, double, float, FD, W>(cfg, io, num_cus, name);
         }
     }
-    if constexpr (spaw_wanted<C, float, F>()) {
+    if constexpr (spaw_wanted<C, float, FF>()) {
+        constexpr int W = FF * C::Z > 64 ? LDPC_SPAW_WAVES_PACKED : LDPC_SPAW_WAVES;
         if (compute_dtype == LDPC_F32 && io.llr_dtype == LDPC_F32)
-            return launch_spaw<RULE, C, float, float, F, W>(cfg, io, num_cus, name);
+            return launch_spaw<RULE, C, float, float, FF, W>(cfg, io, num_cus, name);
     }
     *supported = false;
     return hipSuccess;
@@ -305,8 +321,7 @@ hipError_t LDPC_SPAW_CAT(launch_spec_spaw_rule_, LDPC_SPAW_RULE)(int spec_id, co
     int id = 0;
 #define LDPC_LAUNCH(CODE, SLOTS)                                                                   \
     if (spec_id == id) {                                                                           \
-        constexpr int F = SLOTS * CODE::Z <= 64 ? SLOTS : 1;                                       \
-        return launch_spaw_rule<LDPC_SPAW_RULE, CODE, F>(cfg, compute_dtype, io, num_cus, name, supported); \
+        return launch_spaw_rule<LDPC_SPAW_RULE, CODE, SLOTS>(cfg, compute_dtype, io, num_cus, name, supported); \
     }                                                                                              \
     ++id;
     LDPC_FOR_EACH_SPEC_CODE(LDPC_LAUNCH)
