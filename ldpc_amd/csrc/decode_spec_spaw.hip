@@ -229,6 +229,227 @@ spec_spaw_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t
     }
 }
 
+// ------------------------------------------------------------------------------ independent slots
+// Early exit with several slots per workgroup: every slot runs its own queue of frames, as in
+// spec_r1w_slots_kernel (decode_spec_r1w.hip) - slot s of workgroup b decodes frames
+// (b + k * gridDim.x) * F + s and starts the next one when the current one ends; the slots share
+// the three barriers of an iteration.  Same arithmetic as spec_spaw_kernel; early exit only,
+// max_iters >= 1.
+template <int RULE, class C, typename T, typename TL, int F, int W>
+__global__ void __launch_bounds__(64 * W * ((F * C::Z + 63) / 64))
+spec_spaw_slots_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__restrict__ hard_out,
+                       int *__restrict__ iters_out, uint8_t *__restrict__ conv_out, T *__restrict__ post_out)
+{
+    typedef SpawLayout<C, T, F> LY;
+    typedef R1wPlan<C, W> PL;
+    constexpr int G = (LY::LANES + 63) / 64;
+    constexpr int Z = C::Z, NB = C::NB, ST = sizeof(T);
+    constexpr int n = NB * Z, NBW = PL::NBW, MBW = PL::MBW;
+    extern __shared__ __align__(16) unsigned char smem[];
+
+    const int wave = ((int)threadIdx.x >> 6) / G, lane = (((int)threadIdx.x >> 6) % G) * 64 + ((int)threadIdx.x & 63);
+    const bool lane_on = lane < F * Z;
+    const int f = lane_on ? lane / Z : 0;
+    const int z = lane_on ? lane - f * Z : 0;
+    unsigned char *msg_b = smem + f * LY::SLOT_BYTES;
+    unsigned char *hb_b = msg_b + LY::MSG_BYTES;
+    int *flags = reinterpret_cast<int *>(smem + LY::FLAG_OFF);
+    const unsigned zb = (unsigned)z * ST, z1 = (unsigned)z;
+
+    const long long stride = (long long)gridDim.x * F;
+    long long frame_s[F];  // uniform view of every slot: current frame and iteration
+    int t_s[F];
+    static_for<0, F>([&](auto ff) { frame_s[ff] = (long long)blockIdx.x * F + ff; t_s[ff] = 0; });
+    long long frame = (long long)blockIdx.x * F + f;  // this lane's slot
+    int t = 0;
+    bool live = lane_on && frame < frames;
+
+    T L[NBW], own[NBW];
+    auto load_frame = [&]() {
+        static_for<0, W>([&](auto w) {
+            if (wave == w) {
+                static_for<0, NBW>([&](auto j) {
+                    if constexpr (j < PL::COLS.cnt[w]) {
+                        constexpr int bc = PL::COLS.item[w][j];
+                        constexpr int k0 = C::col_ptr[bc], D = C::col_ptr[bc + 1] - k0;
+                        const T l = (T)llr[frame * n + bc * Z + z];
+                        L[j] = l;
+                        own[j] = l;
+                        hb_b[bc * Z + z1] = (uint8_t)!(l > (T)0);
+                        static_for<0, D>([&](auto k) {  // bpsk.py:299-306: every edge starts with the channel LLR
+                            constexpr int e = C::col_slot[k0 + k], s = C::col_shift[k0 + k];
+                            *reinterpret_cast<T *>(msg_b + e * Z * ST + rot_bwd<Z, ST, s>(zb)) = l;
+                        });
+                    }
+                });
+            }
+        });
+    };
+    static_for<0, NBW>([&](auto j) { L[j] = (T)0; own[j] = (T)0; });
+    if (live) load_frame();
+    if (threadIdx.x < 16) flags[threadIdx.x] = 0;
+    __syncthreads();
+
+    for (int round = 0;; ++round) {
+        bool any_live = false;
+        static_for<0, F>([&](auto ff) { any_live |= frame_s[ff] < frames; });
+        if (!any_live) break;  // uniform: every queue is empty
+        // ---- syndrome of the current hard decisions, this wave's block rows
+        unsigned bad = 0;
+        if (live) {
+            static_for<0, W>([&](auto w) {
+                if (wave == w) {
+                    static_for<0, MBW>([&](auto i) {
+                        if constexpr (i < PL::ROWS.cnt[w]) {
+                            constexpr int br = PL::ROWS.item[w][i];
+                            constexpr int e0 = C::row_ptr[br], D = C::row_ptr[br + 1] - e0;
+                            unsigned hv[D > 0 ? D : 1];
+                            static_for<0, D>([&](auto p) {
+                                constexpr int bc = C::row_col[e0 + p], s = C::row_shift[e0 + p];
+                                hv[p] = hb_b[bc * Z + rot_fwd<Z, 1, s>(z1)];
+                            });
+                            unsigned par = 0;
+                            static_for<0, D>([&](auto p) { par ^= hv[p]; });
+                            bad |= par;
+                        }
+                    });
+                }
+            });
+        }
+        int *slot_bad = flags + (round & 1) * 8;
+        if (bad) slot_bad[f] = 1;
+        __syncthreads();
+        if (threadIdx.x < 8) flags[((round + 1) & 1) * 8 + threadIdx.x] = 0;
+        bool ok_s[F];  // outcome per slot, the same in every wave
+        static_for<0, F>([&](auto ff) { ok_s[ff] = __builtin_amdgcn_readfirstlane(slot_bad[ff]) == 0; });
+        bool slot_ok = ok_s[0];
+        static_for<1, F>([&](auto ff) { if (f == ff) slot_ok = ok_s[ff]; });
+        const bool converged = live && slot_ok;
+        const bool update = live && !slot_ok;
+        // ---- check nodes of this wave's block rows
+        if (update) {
+            static_for<0, W>([&](auto w) {
+                if (wave == w) {
+                    static_for<0, MBW>([&](auto i) {
+                        if constexpr (i < PL::ROWS.cnt[w]) {
+                            constexpr int br = PL::ROWS.item[w][i];
+                            constexpr int e0 = C::row_ptr[br], D = C::row_ptr[br + 1] - e0;
+                            T v[D > 0 ? D : 1];
+                            static_for<0, D>([&](auto p) { v[p] = *reinterpret_cast<const T *>(msg_b + (e0 + p) * Z * ST + zb); });
+                            if constexpr (RULE == 2 || RULE == 3) {  // bpsk.py:325-339, channel.py:471-474
+                                T th[D > 0 ? D : 1], suf[D > 0 ? D : 1];
+                                static_for<0, D>([&](auto p) { th[p] = spa_tanh_half(v[p], g.clip_tanh_arg); });
+                                T run = (T)1;
+                                static_for<0, D>([&](auto pp) { constexpr int p = D - 1 - pp; suf[p] = run; run *= th[p]; });
+                                T pre = (T)1;
+                                static_for<0, D>([&](auto p) {
+                                    *reinterpret_cast<T *>(msg_b + (e0 + p) * Z * ST + zb) =
+                                        spa_message(pre * suf[p], g.clip_prod, g.scale, RULE == 3);
+                                    pre *= th[p];
+                                });
+                            } else {  // channel.py:332-352
+                                T ph[D > 0 ? D : 1], suf[D > 0 ? D : 1];
+                                unsigned neg = 0;
+                                static_for<0, D>([&](auto p) {
+                                    neg |= (unsigned)(v[p] < (T)0) << p;  // 0 and 1e-9 count as +
+                                    ph[p] = phi(t_abs(v[p]));
+                                });
+                                T run = (T)0;
+                                static_for<0, D>([&](auto pp) { constexpr int p = D - 1 - pp; suf[p] = run; run += ph[p]; });
+                                T pre = (T)0;
+                                static_for<0, D>([&](auto p) {
+                                    const bool negative = (__popc(neg & ~(1u << p)) & 1) != 0;
+                                    *reinterpret_cast<T *>(msg_b + (e0 + p) * Z * ST + zb) = phi_message(pre + suf[p], negative);
+                                    pre += ph[p];
+                                });
+                            }
+                        }
+                    });
+                }
+            });
+        }
+        __syncthreads();
+        // ---- variable nodes of this wave's block columns (bpsk.py:346-375, channel.py:358-367, 480-491)
+        if (update) {
+            static_for<0, W>([&](auto w) {
+                if (wave == w) {
+                    static_for<0, NBW>([&](auto j) {
+                        if constexpr (j < PL::COLS.cnt[w]) {
+                            constexpr int bc = PL::COLS.item[w][j];
+                            constexpr int k0 = C::col_ptr[bc], D = C::col_ptr[bc + 1] - k0;
+                            T r[D > 0 ? D : 1], qn[D > 0 ? D : 1];
+                            unsigned off[D > 0 ? D : 1];
+                            static_for<0, D>([&](auto k) {
+                                constexpr int e = C::col_slot[k0 + k], s = C::col_shift[k0 + k];
+                                off[k] = e * Z * ST + rot_bwd<Z, ST, s>(zb);
+                                r[k] = *reinterpret_cast<const T *>(msg_b + off[k]);
+                            });
+                            bool sw[D > 0 ? D : 1];
+                            static_for<0, (D > 0 ? D - 1 : 0)>([&](auto k) {
+                                if constexpr (C::col_pair[k0 + k] != 0) {  // two circulants in one block: lower check index first
+                                    constexpr int s0 = C::col_shift[k0 + k], s1 = C::col_shift[k0 + k + 1];
+                                    sw[k] = rot_bwd<Z, ST, s0>(zb) > rot_bwd<Z, ST, s1>(zb);
+                                    const T a = r[k], b = r[k + 1];
+                                    r[k] = sw[k] ? b : a;
+                                    r[k + 1] = sw[k] ? a : b;
+                                }
+                            });
+                            T run = (T)0;
+                            static_for<0, D>([&](auto k) {
+                                T ext = run;
+                                static_for<k + 1, D>([&](auto kk) { ext += r[kk]; });
+                                run += r[k];
+                                qn[k] = L[j] + ext;
+                            });
+                            static_for<0, (D > 0 ? D - 1 : 0)>([&](auto k) {
+                                if constexpr (C::col_pair[k0 + k] != 0) {
+                                    const T a = qn[k], b = qn[k + 1];
+                                    qn[k] = sw[k] ? b : a;
+                                    qn[k + 1] = sw[k] ? a : b;
+                                }
+                            });
+                            static_for<0, D>([&](auto k) { *reinterpret_cast<T *>(msg_b + off[k]) = qn[k]; });
+                            T b = L[j] + run;
+                            if (g.clip_post > (T)0) b = clip(b, -g.clip_post, g.clip_post);
+                            own[j] = b;
+                            hb_b[bc * Z + z1] = (uint8_t)!(b > (T)0);
+                        }
+                    });
+                }
+            });
+        }
+        // ---- a frame ends with a zero syndrome, or after its last update without a further test
+        const bool ends = converged || (update && t == g.max_iters - 1);
+        if (ends) {
+            static_for<0, W>([&](auto w) {
+                if (wave == w) {
+                    static_for<0, NBW>([&](auto j) {
+                        if constexpr (j < PL::COLS.cnt[w]) {
+                            constexpr int bc = PL::COLS.item[w][j];
+                            hard_out[frame * n + bc * Z + z] = (uint8_t)hard_bit<RULE>(own[j]);
+                            if (post_out) post_out[frame * n + bc * Z + z] = own[j];
+                        }
+                    });
+                }
+            });
+            if (wave == 0 && z == 0) { iters_out[frame] = t; conv_out[frame] = (uint8_t)converged; }
+            frame += stride;
+            t = 0;
+            live = frame < frames;
+            if (live) load_frame();
+        } else if (update) {
+            ++t;
+        }
+        static_for<0, F>([&](auto ff) {  // the uniform copies take the same steps
+            if (frame_s[ff] < frames) {
+                if (ok_s[ff] || t_s[ff] == g.max_iters - 1) { frame_s[ff] += stride; t_s[ff] = 0; }
+                else ++t_s[ff];
+            }
+        });
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------------------ host
 template <int RULE, class C, typename T, typename TL, int F, int W>
 static hipError_t launch_spaw(const ldpc_decode_config &cfg, const Launch &io, int num_cus, const char **name)
@@ -241,6 +462,9 @@ static hipError_t launch_spaw(const ldpc_decode_config &cfg, const Launch &io, i
     g.scale = (T)cfg.scale; g.clip_tanh_arg = (T)cfg.clip_tanh_arg; g.clip_prod = (T)cfg.clip_prod;
     g.clip_post = (T)cfg.clip_post;
     auto k = spec_spaw_kernel<RULE, C, T, TL, F, W>;
+    if constexpr (F > 1) {  // early exit with several slots: every slot runs its own queue of frames
+        if (cfg.early_exit && cfg.max_iters >= 1) k = spec_spaw_slots_kernel<RULE, C, T, TL, F, W>;
+    }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LY::LDS_BYTES);
     if (e != hipSuccess) return e;
