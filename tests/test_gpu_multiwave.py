@@ -98,3 +98,47 @@ def test_empty_batch():
     code = codes.load_packaged("nr_bg2_z40")
     res = decoder_for("nr_bg2_z40").decode(np.zeros((0, code.n)), cfg)
     assert res.hard.shape == (0, code.n) and res.iters.shape == (0,)
+
+
+def test_slot_queues_many_frames_per_slot(c_oracle):
+    """Early exit with several slots per workgroup: every slot walks its own queue of frames.  With
+    far more frames than slots each queue is long; results must land on the right frames."""
+    # sum-product in double on 802.11n (two slots): against the CPU restatement
+    cfg = config.PRESETS["R3"].with_(max_iters=12)
+    code, L = noisy_llrs("wifi648", cfg, 6001, 0.5, 31)
+    eh, ei, ec, ep = c_oracle.c_decode(code, cfg, L)
+    res = decoder_for("wifi648").decode(L, cfg, compute_dtype=np.float64, want_posterior=True)
+    assert res.kernel == "spec_spaw_f64"
+    same = (res.converged == ec) & (res.iters == ei)
+    assert same.mean() >= 0.99
+    assert np.array_equal(res.hard[same & ec], eh[same & ec])
+    scale = np.maximum(np.abs(ep[same]), 1.0)
+    assert float(np.max(np.abs(res.posterior[same] - ep[same]) / scale)) <= 1e-4
+    assert 0.3 < ec.mean() < 1.0 and ei[ec].min() < ei[ec].max()   # frames really end at different times
+
+    # float32 on the BG2-shaped matrix (three slots over two lane groups): every frame is a different
+    # random codeword, so a result written to the wrong frame cannot go unnoticed; iteration counts
+    # against the double kernel, which runs one frame per workgroup
+    name = "nr_bg2_z40"
+    for rule in ("R1", "R3"):
+        cfg = config.PRESETS[rule]
+        code = codes.load_packaged(name)
+        G = codes.load_packaged_generator(name)
+        rng = np.random.default_rng([37, cfg.rule])
+        B = 20011
+        cw = codes.encode(G, rng.integers(0, 2, size=(B, G.shape[0])))
+        snr = -4.0
+        sigma2 = 1.0 / (2.0 * 10 ** (snr / 10))
+        x = 2.0 * cw - 1.0 if cfg.plus_is_bit == 1 else 1.0 - 2.0 * cw
+        L = bp_oracle.llr_from_samples(x + np.sqrt(sigma2) * rng.standard_normal(x.shape), snr, cfg.rule).astype(np.float32)
+        dec = decoder_for(name)
+        r32 = dec.decode(L, cfg, compute_dtype=np.float32)
+        r64 = dec.decode(L, cfg, compute_dtype=np.float64)
+        assert r32.kernel in ("spec_r1w_f32", "spec_spaw_f32")
+        assert r64.converged.mean() > 0.98 and r64.iters.min() < r64.iters.max()
+        assert (r32.converged == r64.converged).mean() >= 0.995
+        both = r32.converged & r64.converged
+        assert np.array_equal(r32.hard[both], r64.hard[both])
+        # (a few frames converge to another codeword at this SNR: undetected errors)
+        assert (r64.hard[r64.converged] == cw.astype(np.uint8)[r64.converged]).all(axis=1).mean() >= 0.999
+        assert (np.abs(r32.iters[both] - r64.iters[both]) <= 1).mean() >= 0.99
