@@ -315,6 +315,7 @@ def other_workloads(code, G, dec, args, torch, dist, device, world, rank):
                                ("BG2_Z40_R1_f64_fixed_10", "R1", "f64"), ("BG2_Z40_R1_f32_fixed_10", "R1", "f32"),
                                ("BG2_Z40_R3_f32_fixed_10", "R3", "f32")]:
         run(label, bg2, None, dec2, rule, dtype, -2.0, False, 32768, k2)
+    run("BG2_Z40_R1_f32_es_n0_-4dB", bg2, None, dec2, "R1", "f32", -4.0, True, 32768, k2)
     return res
 
 
