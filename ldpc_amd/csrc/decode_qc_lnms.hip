@@ -137,7 +137,14 @@ __global__ void qc_lnms_kernel(QcDev q, Cfg<T> g, const TL *__restrict__ llr, lo
                 // ---- syndrome of the hard decisions `0 if P > 0 else 1`
                 unsigned bad = 0;
                 if (!done) {
+                    volatile int *slot_bad_now = slot_bad;  // polled while other waves may still be writing
                     for (int br = 0; br < mb; ++br) {
+                        // a failed test needs no more rows: every four block rows the wave stops if each
+                        // of its running slots has a failure on record (its own lanes' included)
+                        if ((br & 3) == 2) {
+                            if (bad) slot_bad_now[f] = 1;
+                            if (__ballot(slot_bad_now[f] == 0) == 0ull) break;
+                        }
                         unsigned par = 0;
                         for (int e = rptr[br]; e < rptr[br + 1]; ++e) {
                             const unsigned ie = info[e];
