@@ -10,7 +10,8 @@ import os
 from .config import CDecodeConfig
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libldpc_amd.so")
+#: LDPC_AMD_LIB names another build of the same library (kernel experiments); default: in-tree
+LIB_PATH = os.environ.get("LDPC_AMD_LIB") or os.path.join(_HERE, "libldpc_amd.so")
 
 LDPC_OK, LDPC_ERR_ARG, LDPC_ERR_HIP, LDPC_ERR_UNSUPPORTED, LDPC_ERR_NO_DEVICE = range(5)
 F32, F64 = 0, 1

@@ -23,7 +23,12 @@ import shutil
 from . import codes
 
 
+#: frames per workgroup the compiled-in kernels support (size of their per-slot flag arrays)
+MAX_SLOTS = 8
+
+
 def register(name: str, table: str, slots: int = 0) -> dict:
+    slots_given = slots > 0
     if not re.fullmatch(r"[A-Za-z][A-Za-z0-9_]*", name):
         raise ValueError("NAME must be a C identifier")
     if name in codes.PACKAGED or name == "nr_bg1_z384":
@@ -32,6 +37,10 @@ def register(name: str, table: str, slots: int = 0) -> dict:
     codes.compile_qc(qc, name)            # validates the description (raises on repeated edges)
     if slots <= 0:                        # frames per workgroup: fill one wave when Z is small
         slots = max(1, 64 // qc.Z) if qc.Z < 64 else 1
+    if slots > MAX_SLOTS:                 # the kernels keep one syndrome flag per slot in a fixed array
+        if slots_given:
+            raise ValueError(f"--slots {slots}: at most {MAX_SLOTS} frames per workgroup")
+        slots = MAX_SLOTS
     fname = f"{name}.qc.npz"
     dst = os.path.join(os.path.dirname(codes.USER_REGISTRY), fname)
     if os.path.abspath(table) != os.path.abspath(dst):

@@ -7,7 +7,7 @@
 
 namespace ldpc {
 
-constexpr int kMaxCheckDegree = 64;  // sign bits of one check are kept in one 64-bit mask
+constexpr int kMaxCheckDegree = 64;
 
 // Edge lists on the device (all int32).
 struct CsrDev {
@@ -55,10 +55,39 @@ struct Launch {
     hipStream_t stream;
 };
 
+// Device scratch memory of the kernels whose per-frame state does not fit on chip (csr_global_*,
+// qc_lnms_global_*): every resident workgroup owns one slice of it.  `fixed` scratch cannot grow:
+// the launcher then starts only as many workgroups as it holds slices for, and reports
+// hipErrorOutOfMemory (nothing launched) when not even one slice fits.
+struct Scratch {
+    void *ptr = nullptr;
+    size_t bytes = 0;
+    bool fixed = false;
+};
+// Make room for `grid` slices of `per_wg` bytes; may lower `grid` (fixed scratch).  Growing
+// frees and allocates, which synchronises the device: the old buffer is idle by then.
+inline hipError_t scratch_reserve(Scratch &ws, size_t per_wg, long long want_grid, long long &grid)
+{
+    if (ws.fixed) {
+        const long long fit = (long long)(ws.bytes / per_wg);
+        if (fit < 1) return hipErrorOutOfMemory;
+        if (grid > fit) grid = fit;
+        return hipSuccess;
+    }
+    const size_t need = (size_t)want_grid * per_wg;  // sized for the largest grid: no regrowth with the batch size
+    if (ws.bytes < need) {
+        if (ws.ptr) (void)hipFree(ws.ptr);
+        ws.ptr = nullptr; ws.bytes = 0;
+        hipError_t e = hipMalloc(&ws.ptr, need);
+        if (e != hipSuccess) return e;
+        ws.bytes = need;
+    }
+    return hipSuccess;
+}
+
 // decode_csr.hip
 hipError_t launch_csr(const CsrDev &code, const ldpc_decode_config &cfg, int compute_dtype,
-                      const Launch &io, int num_cus, void **workspace, size_t *workspace_bytes,
-                      const char **kernel_name);
+                      const Launch &io, int num_cus, Scratch &workspace, const char **kernel_name);
 // decode_qc_r0.hip (rule 0) and decode_qc.hip, one translation unit per rule (-DLDPC_QC_RULE=k, k = 1..4)
 #define LDPC_DECL_QC(k)                                                                            \
     hipError_t launch_qc_rule_##k(const QcDev &code, const ldpc_decode_config &cfg,                \
@@ -90,8 +119,7 @@ LDPC_DECL_SPAW(2) LDPC_DECL_SPAW(3) LDPC_DECL_SPAW(4)
 #undef LDPC_DECL_SPAW
 // decode_qc_lnms.hip: the same rule for any circulant code, base graph in device tables
 hipError_t launch_qc_lnms(const QcDev &code, const ldpc_decode_config &cfg, int compute_dtype, const Launch &io,
-                          int num_cus, void **workspace, size_t *workspace_bytes, const char **kernel_name,
-                          bool *supported);
+                          int num_cus, Scratch &workspace, const char **kernel_name, bool *supported);
 // count_errors.hip
 hipError_t launch_count_errors(const uint8_t *hard, const uint8_t *ref, long long ref_stride,
                                const int *iters, const uint8_t *conv, long long frames, int n,

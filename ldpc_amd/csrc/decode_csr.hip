@@ -205,8 +205,7 @@ static const size_t kLdsLimit = 160 * 1024;
 
 template <int RULE, typename T, typename TL>
 static hipError_t launch_csr_t(const CsrDev &code, const ldpc_decode_config &cfg, const Launch &io,
-                               int num_cus, void **workspace, size_t *workspace_bytes,
-                               const char **kernel_name)
+                               int num_cus, Scratch &workspace, const char **kernel_name)
 {
     const size_t msgs = (size_t)(RULE == 0 ? 1 : 2) * code.E * sizeof(T);
     const size_t base = (size_t)2 * code.n * sizeof(T) + (size_t)code.n + 16;
@@ -224,15 +223,9 @@ static hipError_t launch_csr_t(const CsrDev &code, const ldpc_decode_config &cfg
     if (where != 0) {
         const size_t hard_elems = ((size_t)code.n + sizeof(T) - 1) / sizeof(T);
         const size_t per_wg = where == 1 ? msgs : msgs + ((size_t)2 * code.n + hard_elems) * sizeof(T);
-        size_t need = (size_t)grid * per_wg;
-        if (*workspace_bytes < need) {
-            if (*workspace) (void)hipFree(*workspace);
-            *workspace = nullptr; *workspace_bytes = 0;
-            hipError_t e = hipMalloc(workspace, need);
-            if (e != hipSuccess) return e;
-            *workspace_bytes = need;
-        }
-        gws = reinterpret_cast<T *>(*workspace);
+        hipError_t e = scratch_reserve(workspace, per_wg, resident, grid);
+        if (e != hipSuccess) return e;
+        gws = reinterpret_cast<T *>(workspace.ptr);
     }
     Cfg<T> g = make_cfg<T>(cfg);
     auto go = [&](auto k, const char *n64, const char *n32) -> hipError_t {
@@ -252,30 +245,29 @@ static hipError_t launch_csr_t(const CsrDev &code, const ldpc_decode_config &cfg
 
 template <typename T, typename TL>
 static hipError_t launch_csr_rule(const CsrDev &code, const ldpc_decode_config &cfg, const Launch &io,
-                                  int num_cus, void **ws, size_t *wsb, const char **name)
+                                  int num_cus, Scratch &ws, const char **name)
 {
     switch (cfg.rule) {
-        case 0: return launch_csr_t<0, T, TL>(code, cfg, io, num_cus, ws, wsb, name);
-        case 1: return launch_csr_t<1, T, TL>(code, cfg, io, num_cus, ws, wsb, name);
-        case 2: return launch_csr_t<2, T, TL>(code, cfg, io, num_cus, ws, wsb, name);
-        case 3: return launch_csr_t<3, T, TL>(code, cfg, io, num_cus, ws, wsb, name);
-        case 4: return launch_csr_t<4, T, TL>(code, cfg, io, num_cus, ws, wsb, name);
+        case 0: return launch_csr_t<0, T, TL>(code, cfg, io, num_cus, ws, name);
+        case 1: return launch_csr_t<1, T, TL>(code, cfg, io, num_cus, ws, name);
+        case 2: return launch_csr_t<2, T, TL>(code, cfg, io, num_cus, ws, name);
+        case 3: return launch_csr_t<3, T, TL>(code, cfg, io, num_cus, ws, name);
+        case 4: return launch_csr_t<4, T, TL>(code, cfg, io, num_cus, ws, name);
     }
     return hipErrorInvalidValue;
 }
 
 hipError_t launch_csr(const CsrDev &code, const ldpc_decode_config &cfg, int compute_dtype,
-                      const Launch &io, int num_cus, void **workspace, size_t *workspace_bytes,
-                      const char **kernel_name)
+                      const Launch &io, int num_cus, Scratch &workspace, const char **kernel_name)
 {
     if (compute_dtype == LDPC_F64) {
         return io.llr_dtype == LDPC_F64
-                   ? launch_csr_rule<double, double>(code, cfg, io, num_cus, workspace, workspace_bytes, kernel_name)
-                   : launch_csr_rule<double, float>(code, cfg, io, num_cus, workspace, workspace_bytes, kernel_name);
+                   ? launch_csr_rule<double, double>(code, cfg, io, num_cus, workspace, kernel_name)
+                   : launch_csr_rule<double, float>(code, cfg, io, num_cus, workspace, kernel_name);
     }
     return io.llr_dtype == LDPC_F64
-               ? launch_csr_rule<float, double>(code, cfg, io, num_cus, workspace, workspace_bytes, kernel_name)
-               : launch_csr_rule<float, float>(code, cfg, io, num_cus, workspace, workspace_bytes, kernel_name);
+               ? launch_csr_rule<float, double>(code, cfg, io, num_cus, workspace, kernel_name)
+               : launch_csr_rule<float, float>(code, cfg, io, num_cus, workspace, kernel_name);
 }
 
 }  // namespace ldpc

@@ -203,6 +203,7 @@ lnms_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__r
     typedef LnPlan<C> PL;
     typedef LnLayout<C, T, F, RL> LY;
     static_assert(PL::supported(), "code shape not supported by the layered kernel");
+    static_assert(F <= 16, "the per-slot syndrome flags are one row of sixteen");
     constexpr int Z = C::Z, NB = C::NB, MB = C::MB, ST = sizeof(T);
     constexpr int n = NB * Z;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -464,18 +465,29 @@ lnms_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__r
                         unsigned sq = 0;
                         unsigned zl = zb;
                         asm volatile("" : "+v"(zl));  // as above: hundreds of hoisted addresses would spill
+                        // all posteriors of the row are requested first, so that the row pays one LDS round
+                        // trip instead of one per edge
                         static_for<0, D>([&](auto p) {
                             if constexpr (p == PP) {
-                                q[p] = lp;  // a variable of degree one always sends its channel LLR
                                 off[p] = 0;
                             } else {
                                 constexpr int bc = C::row_col[e0 + p], s = C::row_shift[e0 + p];
                                 off[p] = ln_addr<LY, PL::lds_index(bc), s>(zl, zbP, zbPW);
-                                const T v = lds_get<T>(off[p]);
+                                q[p] = lds_get<T>(off[p]);
+                            }
+                        });
+                        // bit 31 of ws: sign of the old message on the current edge (one doubling per edge
+                        // instead of one shift by a constant: plain adds issue faster than shifts)
+                        unsigned ws = wp << (31 - (D - 1));
+                        static_for<0, D>([&](auto p) {
+                            if constexpr (p == PP) {
+                                q[p] = lp;  // a variable of degree one always sends its channel LLR
+                            } else {
                                 // previous message of this edge: magnitude B for the old argmin, else A
                                 const T mag = idx_old == p ? Bo : Ao;
-                                q[p] = v - SNum<T>::with_sign(mag, wp << (31 - (D - 1 - p)));
+                                q[p] = q[p] - SNum<T>::with_sign(mag, ws);
                             }
+                            if constexpr (p + 1 < D) asm("v_add_u32 %0, %0, %0" : "+v"(ws));  // the compiler would turn `ws += ws` back into shifts
                             m2 = SNum<T>::second(m1, m2, q[p]);
                             m1 = SNum<T>::min_abs(m1, q[p]);
                             sq = (sq << 1) | (SNum<T>::sign_word(q[p]) >> 31);

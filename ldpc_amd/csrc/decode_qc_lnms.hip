@@ -205,8 +205,7 @@ __global__ void qc_lnms_kernel(QcDev q, Cfg<T> g, const TL *__restrict__ llr, lo
 // ------------------------------------------------------------------------------------------ host
 template <typename T, typename TL>
 static hipError_t launch_qc_lnms_t(const QcDev &code, const ldpc_decode_config &cfg, const Launch &io,
-                                   int num_cus, void **workspace, size_t *workspace_bytes,
-                                   const char **name, bool *supported)
+                                   int num_cus, Scratch &workspace, const char **name, bool *supported)
 {
     *supported = false;
     if (code.max_dc > kMaxLayerDegree) return hipSuccess;
@@ -216,7 +215,7 @@ static hipError_t launch_qc_lnms_t(const QcDev &code, const ldpc_decode_config &
     const size_t FZ = (size_t)F * Z;
     const size_t p_bytes = (size_t)code.nb * FZ * sizeof(T);
     const size_t st_bytes = (size_t)code.mb * FZ * (2 * sizeof(T) + 4);
-    const size_t flags = 64;
+    const size_t flags = (FZ / Z * sizeof(int) + 63) / 64 * 64;  // one syndrome flag per slot
     if (p_bytes + flags > 150 * 1024) return hipSuccess;  // posteriors must fit LDS
     // state beside the posteriors only while that still leaves room for five workgroups per compute unit
     const bool in_lds = p_bytes + st_bytes + flags <= 32 * 1024;
@@ -243,15 +242,9 @@ static hipError_t launch_qc_lnms_t(const QcDev &code, const ldpc_decode_config &
         if (grid < 1) grid = 1;
         unsigned char *ws = nullptr;
         if (!in_lds) {
-            const size_t need = (size_t)grid * st_bytes;
-            if (*workspace_bytes < need) {
-                if (*workspace) (void)hipFree(*workspace);
-                *workspace = nullptr; *workspace_bytes = 0;
-                e = hipMalloc(workspace, need);
-                if (e != hipSuccess) return e;
-                *workspace_bytes = need;
-            }
-            ws = reinterpret_cast<unsigned char *>(*workspace);
+            e = scratch_reserve(workspace, st_bytes, (long long)num_cus * per_cu * 2, grid);
+            if (e != hipSuccess) return e;
+            ws = reinterpret_cast<unsigned char *>(workspace.ptr);
         }
         hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(threads), lds, io.stream, code, g,
                            reinterpret_cast<const TL *>(io.llr), io.frames, io.hard, io.iters, io.converged,
@@ -263,16 +256,16 @@ static hipError_t launch_qc_lnms_t(const QcDev &code, const ldpc_decode_config &
 }
 
 hipError_t launch_qc_lnms(const QcDev &code, const ldpc_decode_config &cfg, int compute_dtype, const Launch &io,
-                          int num_cus, void **workspace, size_t *workspace_bytes, const char **name, bool *supported)
+                          int num_cus, Scratch &workspace, const char **name, bool *supported)
 {
     if (compute_dtype == LDPC_F64) {
         return io.llr_dtype == LDPC_F64
-                   ? launch_qc_lnms_t<double, double>(code, cfg, io, num_cus, workspace, workspace_bytes, name, supported)
-                   : launch_qc_lnms_t<double, float>(code, cfg, io, num_cus, workspace, workspace_bytes, name, supported);
+                   ? launch_qc_lnms_t<double, double>(code, cfg, io, num_cus, workspace, name, supported)
+                   : launch_qc_lnms_t<double, float>(code, cfg, io, num_cus, workspace, name, supported);
     }
     return io.llr_dtype == LDPC_F64
-               ? launch_qc_lnms_t<float, double>(code, cfg, io, num_cus, workspace, workspace_bytes, name, supported)
-               : launch_qc_lnms_t<float, float>(code, cfg, io, num_cus, workspace, workspace_bytes, name, supported);
+               ? launch_qc_lnms_t<float, double>(code, cfg, io, num_cus, workspace, name, supported)
+               : launch_qc_lnms_t<float, float>(code, cfg, io, num_cus, workspace, name, supported);
 }
 
 }  // namespace ldpc

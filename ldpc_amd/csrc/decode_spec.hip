@@ -274,8 +274,10 @@ spec_r1_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *
         static_for<0, NB>([&](auto bc) {
             constexpr int k0 = C::col_ptr[bc], D = C::col_ptr[bc + 1] - k0;
             T l;
-            if constexpr (PREFETCH) l = active ? (T)stage[bc * 64 + tid] : (T)0;
-            else l = active ? (T)llr[frame * n + bc * Z + z] : (T)0;
+            // + 0: a channel value of -0.0 counts as +0.0 (sign(0) := +1, bpsk.py:227-229), and signs are
+            // read from the sign bit from here on
+            if constexpr (PREFETCH) l = (active ? (T)stage[bc * 64 + tid] : (T)0) + (T)0;
+            else l = (active ? (T)llr[frame * n + bc * Z + z] : (T)0) + (T)0;
             L[bc] = l;
             own[bc] = l;
             hm[bc] = __ballot(!(l > (T)0));

@@ -43,6 +43,7 @@ spec_r1w_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t 
     constexpr int Z = C::Z, NB = C::NB, MB = C::MB, ST = sizeof(T), SP = 2 * sizeof(T);
     constexpr int n = NB * Z, NBW = PL::NBW, QW = PL::QW, MBW = PL::MBW;
     extern __shared__ __align__(16) unsigned char smem[];
+    static_assert(F <= 8, "the per-slot syndrome flags are two rows of eight");
 
     const int wave = ((int)threadIdx.x >> 6) / G, lane = (((int)threadIdx.x >> 6) % G) * 64 + ((int)threadIdx.x & 63);
     const bool lane_on = lane < F * Z;
@@ -66,7 +67,7 @@ spec_r1w_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t 
                     if constexpr (j < PL::COLS.cnt[w]) {
                         constexpr int bc = PL::COLS.item[w][j];
                         constexpr int k0 = C::col_ptr[bc], D = C::col_ptr[bc + 1] - k0, q0 = PL::COLS.edge0[w][j];
-                        const T l = active ? (T)llr[frame * n + bc * Z + z] : (T)0;
+                        const T l = (active ? (T)llr[frame * n + bc * Z + z] : (T)0) + (T)0;  // -0.0 -> +0.0: signs are sign bits from here on
                         L[j] = l;
                         own[j] = l;
                         if (lane_on) hb_b[bc * Z + z1] = (uint8_t)hard_bit<1>(l);  // idle lanes alias lane 0
@@ -228,6 +229,7 @@ spec_r1w_slots_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, ui
     constexpr int Z = C::Z, NB = C::NB, ST = sizeof(T), SP = 2 * sizeof(T);
     constexpr int n = NB * Z, NBW = PL::NBW, QW = PL::QW, MBW = PL::MBW;
     extern __shared__ __align__(16) unsigned char smem[];
+    static_assert(F <= 8, "the per-slot syndrome flags are two rows of eight");
 
     const int wave = ((int)threadIdx.x >> 6) / G, lane = (((int)threadIdx.x >> 6) % G) * 64 + ((int)threadIdx.x & 63);
     const bool lane_on = lane < F * Z;
@@ -258,7 +260,7 @@ spec_r1w_slots_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, ui
                     if constexpr (j < PL::COLS.cnt[w]) {
                         constexpr int bc = PL::COLS.item[w][j];
                         constexpr int k0 = C::col_ptr[bc], D = C::col_ptr[bc + 1] - k0, q0 = PL::COLS.edge0[w][j];
-                        const T l = (T)llr[frame * n + bc * Z + z];
+                        const T l = (T)llr[frame * n + bc * Z + z] + (T)0;  // -0.0 -> +0.0
                         L[j] = l;
                         own[j] = l;
                         hb_b[bc * Z + z1] = (uint8_t)hard_bit<1>(l);
@@ -433,6 +435,7 @@ spec_r0w_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t 
     constexpr int Z = C::Z, NB = C::NB, ST = sizeof(T), SP = 2 * sizeof(T);
     constexpr int n = NB * Z, NBW = PL::NBW, MBW = PL::MBW;
     extern __shared__ __align__(16) unsigned char smem[];
+    static_assert(F <= 8, "the per-slot syndrome flags are two rows of eight");
 
     const int wave = ((int)threadIdx.x >> 6) / G, lane = (((int)threadIdx.x >> 6) % G) * 64 + ((int)threadIdx.x & 63);
     const bool lane_on = lane < F * Z;

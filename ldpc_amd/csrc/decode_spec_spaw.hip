@@ -37,6 +37,7 @@ spec_spaw_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t
     constexpr int Z = C::Z, NB = C::NB, ST = sizeof(T);
     constexpr int n = NB * Z, NBW = PL::NBW, MBW = PL::MBW;
     extern __shared__ __align__(16) unsigned char smem[];
+    static_assert(F <= 8, "the per-slot syndrome flags are two rows of eight");
 
     const int wave = ((int)threadIdx.x >> 6) / G, lane = (((int)threadIdx.x >> 6) % G) * 64 + ((int)threadIdx.x & 63);
     const bool lane_on = lane < F * Z;
@@ -246,6 +247,7 @@ spec_spaw_slots_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, u
     constexpr int Z = C::Z, NB = C::NB, ST = sizeof(T);
     constexpr int n = NB * Z, NBW = PL::NBW, MBW = PL::MBW;
     extern __shared__ __align__(16) unsigned char smem[];
+    static_assert(F <= 8, "the per-slot syndrome flags are two rows of eight");
 
     const int wave = ((int)threadIdx.x >> 6) / G, lane = (((int)threadIdx.x >> 6) % G) * 64 + ((int)threadIdx.x & 63);
     const bool lane_on = lane < F * Z;

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "bp_common.h"
@@ -44,8 +45,16 @@ struct ldpc_code {
     int spec_id = -1;       // compiled-in specialisation of this code, if any
     QcDev qc{};
     int *d_qc = nullptr;    // one allocation: row_ptr | row_info | col_ptr | col_info
-    void *workspace = nullptr;
-    size_t workspace_bytes = 0;
+    // scratch of the kernels that keep frame state in global memory, one buffer per stream a decode
+    // was enqueued on: launches on different streams may run at the same time and must not share slices
+    std::vector<std::pair<hipStream_t, Scratch>> workspaces;
+    Scratch &workspace_for(hipStream_t stream)
+    {
+        for (auto &w : workspaces)
+            if (w.first == stream) return w.second;
+        workspaces.emplace_back(stream, Scratch{});
+        return workspaces.back().second;
+    }
 };
 
 extern "C" const char *ldpc_last_error(void) { return g_err.c_str(); }
@@ -223,7 +232,8 @@ extern "C" int32_t ldpc_code_destroy(ldpc_code *c)
     if (!c) return LDPC_OK;
     if (c->d_ints) (void)hipFree(c->d_ints);
     if (c->d_qc) (void)hipFree(c->d_qc);
-    if (c->workspace) (void)hipFree(c->workspace);
+    for (auto &w : c->workspaces)
+        if (w.second.ptr) (void)hipFree(w.second.ptr);
     delete c;
     return LDPC_OK;
 }
@@ -248,10 +258,10 @@ static int check_cfg(const ldpc_decode_config *cfg)
     return LDPC_OK;
 }
 
-extern "C" int32_t ldpc_decode_batch(ldpc_code *c, const ldpc_decode_config *cfg, const void *llr_dev,
-                                     int32_t llr_dtype, int32_t compute_dtype, int32_t kernel,
-                                     int64_t frames, uint8_t *hard_dev, int32_t *iters_dev,
-                                     uint8_t *converged_dev, void *posterior_dev, void *stream)
+static int decode_impl(ldpc_code *c, const ldpc_decode_config *cfg, const void *llr_dev,
+                       int32_t llr_dtype, int32_t compute_dtype, int32_t kernel,
+                       int64_t frames, uint8_t *hard_dev, int32_t *iters_dev,
+                       uint8_t *converged_dev, void *posterior_dev, void *stream)
 {
     if (!c) return fail(LDPC_ERR_ARG, "code is NULL");
     if (int rc = check_cfg(cfg)) return rc;
@@ -265,13 +275,18 @@ extern "C" int32_t ldpc_decode_batch(ldpc_code *c, const ldpc_decode_config *cfg
 
     Launch io{llr_dev, llr_dtype, (long long)frames, hard_dev, iters_dev, converged_dev, posterior_dev,
               reinterpret_cast<hipStream_t>(stream)};
+    Scratch &ws = c->workspace_for(io.stream);
     // the loop-bound quirks exist only in the edge-list kernel
     const bool quirks = (cfg->rule == 0 && cfg->num_active_checks >= 0 && cfg->num_active_checks < c->m) ||
                         (cfg->rule != 0 && cfg->num_refresh_vars >= 0 && cfg->num_refresh_vars < c->n);
     if (kernel == LDPC_KERNEL_QC && !c->has_qc) return fail(LDPC_ERR_ARG, "no QC description attached to this code");
     if (kernel == LDPC_KERNEL_QC && quirks)
         return fail(LDPC_ERR_UNSUPPORTED, "num_active_checks / num_refresh_vars need the edge-list kernel");
-    if (kernel == LDPC_KERNEL_AUTO && c->has_qc && !quirks && c->spec_id >= 0) {
+    if (cfg->rule == LDPC_RULE_LNMS && (quirks || (cfg->num_active_checks >= 0 && cfg->num_active_checks < c->m) || cfg->clip_post > 0.0))
+        return fail(LDPC_ERR_UNSUPPORTED, "layered min-sum has no num_active_checks / num_refresh_vars / clip_post");
+    // the compiled-in R1 kernels carry no posterior clip (the reference's R1 has none, bpsk.py:235-237)
+    const bool spec_ok = !(cfg->rule == LDPC_RULE_R1 && cfg->clip_post > 0.0);
+    if (kernel == LDPC_KERNEL_AUTO && c->has_qc && !quirks && c->spec_id >= 0 && spec_ok) {
         bool supported = false;
         hipError_t e = launch_spec(c->spec_id, *cfg, compute_dtype, io, c->num_cus, &g_kernel, &supported);
         if (e != hipSuccess) return fail(LDPC_ERR_HIP, "specialised kernel launch: %s", hipGetErrorString(e));
@@ -280,8 +295,7 @@ extern "C" int32_t ldpc_decode_batch(ldpc_code *c, const ldpc_decode_config *cfg
     if (cfg->rule == LDPC_RULE_LNMS) {
         if (kernel != LDPC_KERNEL_CSR && c->has_qc && !c->qc_pairs) {
             bool supported = false;
-            hipError_t e = launch_qc_lnms(c->qc, *cfg, compute_dtype, io, c->num_cus, &c->workspace, &c->workspace_bytes,
-                                          &g_kernel, &supported);
+            hipError_t e = launch_qc_lnms(c->qc, *cfg, compute_dtype, io, c->num_cus, ws, &g_kernel, &supported);
             if (e != hipSuccess) return fail(LDPC_ERR_HIP, "layered kernel launch: %s", hipGetErrorString(e));
             if (supported) return LDPC_OK;
         }
@@ -303,9 +317,18 @@ extern "C" int32_t ldpc_decode_batch(ldpc_code *c, const ldpc_decode_config *cfg
         if (kernel == LDPC_KERNEL_QC)
             return fail(LDPC_ERR_UNSUPPORTED, "circulant kernel cannot serve this code/dtype (LDS footprint or degree)");
     }
-    hipError_t e = launch_csr(c->csr, *cfg, compute_dtype, io, c->num_cus, &c->workspace, &c->workspace_bytes, &g_kernel);
+    hipError_t e = launch_csr(c->csr, *cfg, compute_dtype, io, c->num_cus, ws, &g_kernel);
     if (e != hipSuccess) return fail(LDPC_ERR_HIP, "edge-list kernel launch: %s", hipGetErrorString(e));
     return LDPC_OK;
+}
+
+extern "C" int32_t ldpc_decode_batch(ldpc_code *c, const ldpc_decode_config *cfg, const void *llr_dev,
+                                     int32_t llr_dtype, int32_t compute_dtype, int32_t kernel,
+                                     int64_t frames, uint8_t *hard_dev, int32_t *iters_dev,
+                                     uint8_t *converged_dev, void *posterior_dev, void *stream)
+{
+    return decode_impl(c, cfg, llr_dev, llr_dtype, compute_dtype, kernel, frames, hard_dev, iters_dev,
+                       converged_dev, posterior_dev, stream);
 }
 
 extern "C" int32_t ldpc_decode_batch_host(ldpc_code *c, const ldpc_decode_config *cfg, const void *llr,

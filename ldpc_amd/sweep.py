@@ -32,50 +32,85 @@ class DeviceBatch:
     counters: "torch.Tensor"   # [5] int64 (the library adds into it as uint64)
 
 
-def make_batch(code: CompiledCode, G: Optional[np.ndarray], frames: int, snr_db: float,
-               cfg: DecodeConfig, seed, device, llr_dtype=None, llr_scale_snr_db: Optional[float] = None,
-               native_noise: bool = False, first_frame: int = 0) -> DeviceBatch:
-    """Random codewords (all-zero if ``G`` is None; ``G`` is a k x n generator matrix or a callable
-    encoder with attribute ``k``), BPSK with the polarity ``cfg`` expects, AWGN
-    of variance 1/(2*10^(snr/10)) (ldpc.py:245), LLR = 2y/sigma^2 (y/sigma^2 for R2)."""
+def make_codewords(code: CompiledCode, G, frames: int, seed, device) -> "torch.Tensor":
+    """[frames, n] uint8 codewords of random messages on the device: all-zero if ``G`` is None, else
+    ``G`` is a k x n generator matrix (msg @ G mod 2, the reference's ldpc.py:46 with G transposed)
+    or a callable encoder with attribute ``k``."""
     import torch
 
-    llr_dtype = llr_dtype or torch.float32
-    gen = torch.Generator(device=device)
-    gen.manual_seed(int(np.random.SeedSequence(seed).generate_state(1)[0]))
     n = code.n
     if G is None:
-        cw = torch.zeros((frames, n), dtype=torch.uint8, device=device)
-    elif callable(G):  # structured encoder (host side), e.g. nr_bg1.Encoder: messages of G.k bits
+        return torch.zeros((frames, n), dtype=torch.uint8, device=device)
+    cw = torch.empty((frames, n), dtype=torch.uint8, device=device)
+    if callable(G):  # structured encoder: a device encoder (takes and returns tensors) or a host one
+        on_device = getattr(G, "on_device", False)
         host_rng = np.random.default_rng(np.random.SeedSequence(seed).generate_state(2))
-        cw = torch.empty((frames, n), dtype=torch.uint8, device=device)
         step = max(1, (1 << 26) // max(n, 1))
         for a in range(0, frames, step):
             b = min(frames, a + step)
-            cw[a:b] = torch.as_tensor(G(host_rng.integers(0, 2, size=(b - a, G.k), dtype=np.uint8)), device=device)
-    else:
-        Gt = torch.as_tensor(np.ascontiguousarray(G), dtype=torch.float32, device=device)
-        cw = torch.empty((frames, n), dtype=torch.uint8, device=device)
-        step = max(1, (1 << 28) // max(n, 1))
-        for a in range(0, frames, step):
-            b = min(frames, a + step)
-            msg = torch.randint(0, 2, (b - a, Gt.shape[0]), generator=gen, device=device, dtype=torch.int32)
-            cw[a:b] = torch.remainder(msg.to(torch.float32) @ Gt, 2.0).to(torch.uint8)
-    if native_noise:
-        # noise and LLRs from the library's own kernel: frame f gets the noise of absolute frame
-        # first_frame + f, whatever batch or rank it is generated in
-        from . import channel
-        llr = torch.empty((frames, n), dtype=llr_dtype, device=device)
-        key = int(np.random.SeedSequence(seed).generate_state(1, dtype=np.uint64)[0])
+            msg = host_rng.integers(0, 2, size=(b - a, G.k), dtype=np.uint8)
+            if on_device:
+                cw[a:b] = G(torch.as_tensor(msg, device=device))
+            else:
+                cw[a:b] = torch.as_tensor(G(msg), device=device)
+        return cw
+    gen = torch.Generator(device=device)
+    gen.manual_seed(int(np.random.SeedSequence(seed).generate_state(1)[0]))
+    Gt = torch.as_tensor(np.ascontiguousarray(G), dtype=torch.float32, device=device)
+    step = max(1, (1 << 28) // max(n, 1))
+    for a in range(0, frames, step):
+        b = min(frames, a + step)
+        msg = torch.randint(0, 2, (b - a, Gt.shape[0]), generator=gen, device=device, dtype=torch.int32)
+        cw[a:b] = torch.remainder(msg.to(torch.float32) @ Gt, 2.0).to(torch.uint8)
+    return cw
+
+
+def _empty_outputs(cw, llr, device):
+    import torch
+
+    frames, n = cw.shape
+    return DeviceBatch(llr, cw,
+                       torch.empty((frames, n), dtype=torch.uint8, device=device),
+                       torch.empty((frames,), dtype=torch.int32, device=device),
+                       torch.empty((frames,), dtype=torch.uint8, device=device),
+                       torch.zeros((5,), dtype=torch.int64, device=device))
+
+
+def noisy_batch(code: CompiledCode, cw, snr_db: float, cfg: DecodeConfig, seed, device, llr_dtype=None,
+                llr_scale_snr_db: Optional[float] = None, first_frame: int = 0) -> DeviceBatch:
+    """Channel LLRs for the codewords ``cw`` from the library's own kernel (ldpc_channel_llr): frame
+    f gets the noise of absolute frame ``first_frame + f``, whatever batch or rank generates it."""
+    import torch
+
+    from . import channel
+    llr_dtype = llr_dtype or torch.float32
+    frames, n = cw.shape
+    llr = torch.empty((frames, n), dtype=llr_dtype, device=device)
+    key = int(np.random.SeedSequence(seed).generate_state(1, dtype=np.uint64)[0])
+    if frames:
         channel.channel_llr_device(cw.data_ptr(), n, frames, n, snr_db, cfg, key, first_frame, llr.data_ptr(),
                                    np.float32 if llr_dtype == torch.float32 else np.float64,
                                    stream=torch.cuda.current_stream().cuda_stream,
                                    llr_scale_snr_db=llr_scale_snr_db)
-        return DeviceBatch(llr, cw,
-                           torch.empty((frames, n), dtype=torch.uint8, device=device),
-                           torch.empty((frames,), dtype=torch.int32, device=device),
-                           torch.empty((frames,), dtype=torch.uint8, device=device),
-                           torch.zeros((5,), dtype=torch.int64, device=device))
+    return _empty_outputs(cw, llr, device)
+
+
+def make_batch(code: CompiledCode, G: Optional[np.ndarray], frames: int, snr_db: float,
+               cfg: DecodeConfig, seed, device, llr_dtype=None, llr_scale_snr_db: Optional[float] = None,
+               native_noise: bool = False, first_frame: int = 0) -> DeviceBatch:
+    """Random codewords (``make_codewords``), BPSK with the polarity ``cfg`` expects, AWGN
+    of variance 1/(2*10^(snr/10)) (ldpc.py:245), LLR = 2y/sigma^2 (y/sigma^2 for R2).  Noise comes
+    from the library's channel kernel (``native_noise``) or from torch's generator."""
+    import torch
+
+    llr_dtype = llr_dtype or torch.float32
+    n = code.n
+    cw = make_codewords(code, G, frames, seed, device)
+    if native_noise:
+        return noisy_batch(code, cw, snr_db, cfg, seed, device, llr_dtype=llr_dtype,
+                           llr_scale_snr_db=llr_scale_snr_db, first_frame=first_frame)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(int(np.random.SeedSequence(list(np.atleast_1d(seed)) + [1]).generate_state(1)[0]))
     sigma2 = 1.0 / (2.0 * 10.0 ** (snr_db / 10.0))
     sigma2_llr = sigma2 if llr_scale_snr_db is None else 1.0 / (2.0 * 10.0 ** (llr_scale_snr_db / 10.0))
     gain = (1.0 if cfg.rule == 2 else 2.0) / sigma2_llr
@@ -87,11 +122,7 @@ def make_batch(code: CompiledCode, G: Optional[np.ndarray], frames: int, snr_db:
         x = 2.0 * c - 1.0 if cfg.plus_is_bit == 1 else 1.0 - 2.0 * c
         noise = torch.randn((b - a, n), generator=gen, device=device, dtype=torch.float64)
         llr[a:b] = ((x + (sigma2 ** 0.5) * noise) * gain).to(llr_dtype)
-    return DeviceBatch(llr, cw,
-                       torch.empty((frames, n), dtype=torch.uint8, device=device),
-                       torch.empty((frames,), dtype=torch.int32, device=device),
-                       torch.empty((frames,), dtype=torch.uint8, device=device),
-                       torch.zeros((5,), dtype=torch.int64, device=device))
+    return _empty_outputs(cw, llr, device)
 
 
 def decode_batch(dec: Decoder, batch: DeviceBatch, cfg: DecodeConfig, compute_dtype=np.float64,
@@ -149,29 +180,72 @@ def summarize(counters: np.ndarray, n: int) -> dict:
     return c
 
 
+def _rank_world(rank, world):
+    """Rank and world size: the arguments when given, else torch.distributed's, else (0, 1)."""
+    if rank is not None and world is not None:
+        return int(rank), int(world)
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+#: frames per seeding unit of a sweep: the codewords of absolute frames [c * CHUNK, (c + 1) * CHUNK)
+#: of an SNR point come from seed [seed, point, c], whichever rank decodes them
+SWEEP_CHUNK = 1 << 14
+
+
 def ber_sweep(code: CompiledCode, G: Optional[np.ndarray], cfg: DecodeConfig, snrs_db, frames_per_point: int,
-              device, compute_dtype=np.float64, seed=0, dec: Optional[Decoder] = None, batch: int = 1 << 18):
+              device, compute_dtype=np.float64, seed=0, dec: Optional[Decoder] = None, batch: int = 1 << 18,
+              rank: Optional[int] = None, world: Optional[int] = None, reduce: bool = True):
     """Monte-Carlo error-rate sweep, the batched form of the reference's ``plotFrameError``
-    (ldpc.py:637-667): per SNR point decode ``frames_per_point`` random frames on this rank, count
-    on the device, sum the counters over ranks.  Returns one summary dict per SNR point."""
+    (ldpc.py:637-667).  The ``frames_per_point`` frames of an SNR point are numbered 0, 1, ...; rank r
+    of ``world`` decodes the contiguous range ``shard_range(frames_per_point, r, world)`` of them,
+    counts on the device, and the counters are summed over the ranks (one all-reduce per point).
+    A frame's codeword and noise depend on (seed, point, absolute frame number) only, so the summed
+    counters are the same for every ``world``.  Returns one summary dict per SNR point."""
     import torch
 
+    rank, world = _rank_world(rank, world)
     dec = dec or Decoder(code)
+    per_launch = max(SWEEP_CHUNK, batch // SWEEP_CHUNK * SWEEP_CHUNK)
     out = []
     for si, snr in enumerate(snrs_db):
         total = torch.zeros((5,), dtype=torch.int64, device=device)
-        left, chunk = frames_per_point, 0
-        while left > 0:
-            b = min(left, batch)
-            bt = make_batch(code, G, b, float(snr), cfg, seed=[seed, si, chunk], device=device)
+        a, b = shard_range(frames_per_point, rank, world)
+        pos = a
+        while pos < b:
+            # one launch: the part of [pos, b) that lies in the next `per_launch`-aligned window
+            end = min(b, (pos // per_launch + 1) * per_launch)
+            bt = make_batch_range(code, G, pos, end, frames_per_point, float(snr), cfg, seed=[seed, si], device=device)
             decode_batch(dec, bt, cfg, compute_dtype=compute_dtype)
             count_errors(dec, bt)
             total += bt.counters
-            left -= b
-            chunk += 1
-        allreduce_counters(total)
+            pos = end
+        if reduce:
+            allreduce_counters(total)
         torch.cuda.synchronize()
         summ = summarize(total.cpu().numpy(), code.n)
         summ["es_n0_db"] = float(snr)
         out.append(summ)
     return out
+
+
+def make_batch_range(code: CompiledCode, G, first: int, last: int, total: int, snr_db: float, cfg: DecodeConfig,
+                     seed, device, llr_dtype=None) -> DeviceBatch:
+    """The frames [first, last) of a sweep point of ``total`` frames.  Codewords are drawn per
+    ``SWEEP_CHUNK``-aligned chunk of absolute frame numbers (seed + [chunk]), noise comes from the
+    library's channel kernel keyed by the absolute frame number: the result does not depend on how
+    the point is cut into ranges."""
+    import torch
+
+    seed = list(np.atleast_1d(seed))
+    parts = []
+    for c in range(first // SWEEP_CHUNK, (last + SWEEP_CHUNK - 1) // SWEEP_CHUNK):
+        c0 = c * SWEEP_CHUNK
+        c1 = min(total, c0 + SWEEP_CHUNK)
+        cw = make_codewords(code, G, c1 - c0, seed + [c], device)
+        parts.append(cw[max(first, c0) - c0:min(last, c1) - c0])
+    cw = parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
+    return noisy_batch(code, cw, snr_db, cfg, seed, device, llr_dtype=llr_dtype, first_frame=first)
