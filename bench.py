@@ -1,25 +1,31 @@
 #!/usr/bin/env python3
-"""Throughput of the batched LDPC decoder on MI355X: decoded info Gbit/s.
+"""Throughput of the batched LDPC decoder on MI355X: decoded info Gbit/s at 10 BP iterations.
 
     python bench.py --gpus 1 --steps 10 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One step = one decode launch over a batch of synthetic frames resident in HBM.  The default
-workload is the CCSDS (512,256) code, 2^20 frames per launch and per GPU, the reference's own
-ldpc.py decoder (rule R0, at most 10 iterations with a syndrome check at the top of each), float64
-arithmetic (bit-exact with the reference), at an SNR low enough that practically every frame uses
-the whole iteration budget — so "10 BP iterations" are really executed.  Frames are independent:
-every rank decodes its own batch (weak scaling) and the ranks meet only in the all-reduce of the
-error counters.
+One step = one decode launch over a batch of synthetic frames resident in HBM.  Frames are
+independent: every rank decodes its own batch (weak scaling) and the ranks meet only in the
+all-reduce of the error counters.
 
-Rank 0 prints one JSON line.  Beside the headline value it carries
+Headline (`value`): CCSDS (512,256), 2^20 frames per launch and per GPU, the reference's own ldpc.py
+decoder (rule R0), exactly 10 iterations per frame (no early exit), float64 arithmetic (bit-exact
+with the reference).  The same kernel with the reference's per-iteration syndrome check at an
+operating SNR is reported beside it as `operating_point`, and with that check at an SNR where no
+frame converges as `worst_case_early_exit`.
+
+Rank 0 prints one JSON line.  Beside the headline it carries
   roofline      algorithmic HBM bytes per launch / measured kernel time, against 8 TB/s
-  lds_roofline  algorithmic LDS bytes of the executed iterations against the nominal LDS rate
-  valu_roofline vector instructions issued (counter pass on file) against the nominal issue rate
+  lds_roofline  algorithmic LDS bytes of the executed iterations against the LDS rates of the
+                instruction widths involved
+  valu_roofline vector instructions issued (counter pass on file, only while the kernel source is
+                unchanged since) against the nominal issue rate
   cpu_baseline  the CPU restatement (oracle/bp_oracle.c, OpenMP) timed on a bounded sample of the
                 same LLRs on this host, which doubles as a parity check of that sample
-  other         secondary workloads (early exit at an operating SNR, float32, rules R1 and R3, BG2-shaped 5G matrix, NR BG1
-                Z=384 layered min-sum), aggregated over all ranks like the headline
+  bg1           the other half of the metric: NR BG1 Z=384 (build-authored table) under row-layered
+                min-sum, exactly 10 sweeps, in float32 and float64, each with its own rooflines and
+                CPU baseline, plus early-exit operating points
+  other         secondary workloads, aggregated over all ranks like the headline
 """
 import argparse
 import glob
@@ -34,53 +40,70 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E peak
-LDS_PEAK_GBS = 128 * 256 * 2.4   # 128 B/clk/CU x 256 CUs x 2.4 GHz = 78.6 TB/s (nominal)
+# LDS rates with every CU streaming (GB/s): 4-byte reads, 8/16-byte reads, writes (38-51 TB/s measured
+# for ds_write_b32...b128; the midpoint is used)
+LDS_READ32_GBS, LDS_READ64_GBS, LDS_WRITE_GBS = 75e3, 150e3, 45e3
+VALU_PEAK_GIPS = 256 * 4 * 2.4 / 4   # one wave-instruction per SIMD every 4 cycles at 2.4 GHz
 
 
 def lds_bytes_per_frame_iter(code, rule, itemsize):
-    """Algorithmic LDS traffic of one iteration of one frame: flooding extrinsic rules read and
-    write one message per edge in both phases (16 E), R0 12 E + 4 n, layered min-sum reads and
-    writes one posterior per edge (8 E) plus its compressed check state (24 m)."""
-    E, n = code.num_edges, code.n
-    per4 = (12 * E + 4 * n) if rule == 0 else (8 * E + 24 * code.m if rule == 5 else 16 * E)
-    return per4 * itemsize // 4
+    """Algorithmic LDS traffic of one iteration of one frame as (bytes read, bytes written), for
+    4-byte numbers scaled by the item size: flooding extrinsic rules read and write one message per
+    edge in both phases (8 E + 8 E); R0 reads 8 E and writes 4 E + 4 n; layered min-sum reads and
+    writes one posterior per edge and its compressed check state (4 E + 12 m each way)."""
+    E, n, m = code.num_edges, code.n, code.m
+    if rule == 0:
+        r, w = 8 * E, 4 * E + 4 * n
+    elif rule == 5:
+        r, w = 4 * E + 12 * m, 4 * E + 12 * m
+    else:
+        r, w = 8 * E, 8 * E
+    return r * itemsize // 4, w * itemsize // 4
 
 
-def measured_traffic(args, frames):
-    """HBM bytes per launch from the hardware counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3
-    passes, corrected as profiles/*_hbm_traffic.json says), scaled to this launch's frame count;
-    None when no counter run is on file for this workload."""
-    key = f"{args.code}/{args.rule}/{args.dtype}/f32llr"
+def _profile_record(kind, key, fixed, kernel):
+    """Newest counter record on file for this workload whose kernel source is unchanged since."""
+    from ldpc_amd.build import kernel_source_digest
     best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json"))):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{kind}.json"))):
         try:
             rec = json.load(open(path))["workloads"].get(key)
         except (OSError, ValueError, KeyError):
             rec = None
-        if rec and rec.get("early_exit", True) == (not args.fixed):
-            best = rec["hbm_bytes_per_frame"] * frames
+        if rec and rec.get("early_exit", True) == (not fixed) and rec.get("kernel") == kernel \
+                and rec.get("kernel_source_sha16") == kernel_source_digest(kernel):
+            best = dict(rec, source=os.path.basename(path))
     return best
 
 
-def valu_roofline(args, executed_frame_iters, kernel_ms):
-    """Vector-issue bound: wave-instructions per second against one instruction per SIMD every 4
-    cycles (256 CUs x 4 SIMDs x 2.4 GHz / 4).  The instruction count per frame-iteration comes from
-    the SQ_INSTS_VALU pass on file for this workload (profiles/*_sq_counters.json)."""
-    key = f"{args.code}/{args.rule}/{args.dtype}/f32llr"
-    per = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sq_counters.json"))):
-        try:
-            rec = json.load(open(path))["workloads"].get(key)
-        except (OSError, ValueError, KeyError):
-            rec = None
-        if rec and rec.get("early_exit", True) == (not args.fixed):
-            per = rec["valu_wave_instructions_per_frame_iteration"]
-    if per is None:
-        return None
-    peak = 256 * 4 * 2.4e9 / 4 / 1e9
-    achieved = per * executed_frame_iters / (kernel_ms * 1e-3) / 1e9
-    return {"bound": "valu", "achieved": achieved, "peak": peak, "unit": "G wave-instructions/s",
-            "frac": achieved / peak, "valu_per_frame_iteration": per}
+def rooflines(code, cfg, dtype, frames, kernel_ms, executed, kernel, code_name, rule_name):
+    """HBM, LDS and vector-issue rooflines of one launch."""
+    itemsize = 8 if dtype == "f64" else 4
+    key = f"{code_name}/{rule_name}/{dtype}/f32llr"
+    fixed = not cfg.early_exit
+    sec = kernel_ms * 1e-3
+    hbm_bytes = (5 * code.n + 5) * frames                 # f32 LLR in, u8 hard + i32 + u8 out
+    tr = _profile_record("hbm_traffic", key, fixed, kernel)
+    roof = {"bound": "hbm", "achieved": hbm_bytes / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "traffic": tr["hbm_bytes_per_frame"] * frames if tr else None,
+            "traffic_source": tr["source"] if tr else None,
+            "kernel": kernel, "kernel_ms": kernel_ms, "bytes_per_frame": 5 * code.n + 5}
+    roof["frac"] = roof["achieved"] / roof["peak"]
+    rd, wr = lds_bytes_per_frame_iter(code, cfg.rule, itemsize)
+    floor = executed * (rd / ((LDS_READ64_GBS if itemsize == 8 else LDS_READ32_GBS) * 1e9) + wr / (LDS_WRITE_GBS * 1e9))
+    lds = {"bound": "lds", "achieved": (rd + wr) * executed / sec / 1e9, "unit": "GB/s",
+           "read_bytes_per_frame_iter": rd, "write_bytes_per_frame_iter": wr,
+           "rates_gb_s": {"read": LDS_READ64_GBS if itemsize == 8 else LDS_READ32_GBS, "write": LDS_WRITE_GBS}}
+    lds["peak"] = (rd + wr) * executed / floor / 1e9      # rate at which this read/write mix could move at best
+    lds["frac"] = lds["achieved"] / lds["peak"]
+    out = {"roofline": roof, "lds_roofline": lds}
+    sq = _profile_record("sq_counters", key, fixed, kernel)
+    if sq:
+        per = sq["valu_wave_instructions_per_frame_iteration"]
+        ach = per * executed / sec / 1e9
+        out["valu_roofline"] = {"bound": "valu", "achieved": ach, "peak": VALU_PEAK_GIPS, "unit": "G wave-instructions/s",
+                                "frac": ach / VALU_PEAK_GIPS, "valu_per_frame_iteration": per, "source": sq["source"]}
+    return out
 
 
 def timed_steps(fn, steps, warmup, torch, dist, world):
@@ -110,23 +133,98 @@ def timed_steps(fn, steps, warmup, torch, dist, world):
     return wall, dev_ms
 
 
+class Runner:
+    """One (code, decoder) pair and the measurement of a workload on it."""
+
+    def __init__(self, name, torch, dist, device, world, rank):
+        from ldpc_amd import codes
+        from ldpc_amd.decoder import Decoder
+        self.name, self.torch, self.dist, self.device, self.world, self.rank = name, torch, dist, device, world, rank
+        self.code = codes.load_packaged(name)
+        self.G = codes.load_packaged_generator(name) if name in ("ccsds512", "wifi648", "nr_bg1_z384") else None
+        self.k = (self.G.k if callable(self.G) else self.G.shape[0]) if self.G is not None else self.code.n - self.code.m
+        self.dec = Decoder(self.code)
+
+    def run(self, rule, dtype, snr, early, frames, steps, warmup, max_iters=10, seed=7, kernel=0, with_rooflines=False):
+        from ldpc_amd import config, sweep
+        cfg = config.PRESETS[rule].with_(max_iters=max_iters, early_exit=early)
+        batch = sweep.make_batch(self.code, self.G, frames, snr, cfg, seed=[seed, self.rank], device=self.device)
+        compute = np.float64 if dtype == "f64" else np.float32
+        kname = [""]
+
+        def step():
+            kname[0] = sweep.decode_batch(self.dec, batch, cfg, compute_dtype=compute, kernel=kernel)
+
+        wall, dev_ms = timed_steps(step, steps, warmup, self.torch, self.dist, self.world)
+        # error counters of the last step, summed over ranks: the one collective of the path
+        batch.counters.zero_()
+        sweep.count_errors(self.dec, batch)
+        sweep.allreduce_counters(batch.counters)
+        self.torch.cuda.synchronize()
+        st = sweep.summarize(batch.counters.cpu().numpy(), self.code.n)
+        res = {"value": frames * self.world * steps * self.k / wall / 1e9, "unit": "Gbit/s", "ms_per_step": wall / steps * 1e3,
+               "kernel": kname[0], "kernel_ms": dev_ms / steps, "code": self.name, "rule": rule, "dtype": dtype,
+               "frames_per_launch_per_gpu": frames, "max_iters": max_iters, "early_exit": early, "es_n0_db": snr,
+               "mean_iters": st["mean_iters"], "fer": st["fer"], "ber": st["ber"],
+               "counters": {k: st[k] for k in sweep.COUNTER_NAMES}}
+        if with_rooflines:
+            # iterations actually run: failures ran max_iters but report max-1; fixed mode reports max_iters
+            executed = (st["iterations"] + (st["not_converged"] if early else 0)) / self.world
+            res.update(rooflines(self.code, cfg, dtype, frames, dev_ms / steps, executed, kname[0], self.name, rule))
+        return res, batch, cfg
+
+
+def cpu_baseline(code, cfg, batch, k_info, dtype, seconds, cpu_sample=0):
+    """CPU restatement on a bounded sample of the same LLRs, all host threads of this process's
+    share; also checks that the GPU's results for that sample are identical."""
+    from oracle import bp_oracle
+    bp_oracle.build_c_oracle()
+    threads = min(bp_oracle.c_max_threads(), len(os.sched_getaffinity(0)), 64)
+    if cfg.rule == 5:
+        decode = lambda x: bp_oracle.c_decode_lnms(code, cfg, x, nthreads=threads, use_float=dtype == "f32",
+                                                   want_posterior=False)
+    else:
+        decode = lambda x: bp_oracle.c_decode(code, cfg, x, nthreads=threads, want_posterior=False)
+    probe = (64 if code.n <= 1024 else 2) * threads
+    L = batch.llr[:probe].cpu().numpy().astype(np.float64)
+    t0 = time.perf_counter()
+    decode(L)
+    rate = probe / max(time.perf_counter() - t0, 1e-6)
+    sample = cpu_sample or int(min(batch.llr.shape[0], max(probe, rate * seconds)))
+    L = batch.llr[:sample].cpu().numpy().astype(np.float64)
+    t0 = time.perf_counter()
+    hard, iters, conv, _ = decode(L)
+    dt = time.perf_counter() - t0
+    same = (np.array_equal(hard, batch.hard[:sample].cpu().numpy())
+            and np.array_equal(iters, batch.iters[:sample].cpu().numpy())
+            and np.array_equal(conv, batch.converged[:sample].cpu().numpy().astype(bool)))
+    exact = dtype == "f64" or cfg.rule == 5
+    return {"value": sample * k_info / dt / 1e9, "unit": "Gbit/s", "cores": threads, "kind": "port",
+            "sample": f"first {sample} frames of the same LLR batch, "
+                      f"{'float32' if (cfg.rule == 5 and dtype == 'f32') else 'float64'}, oracle/bp_oracle.c with "
+                      f"{threads} OpenMP threads, {dt:.1f} s",
+            "gpu_results_identical_on_sample": bool(same) if exact else None}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=0, help="frames per launch per GPU (0: 2^20 for the "
-                    "small codes, as many as give about 3 GiB of LLRs for the large ones)")
+                    "small codes, 16384 for the NR graphs)")
     ap.add_argument("--code", default="ccsds512")
     ap.add_argument("--rule", default="R0")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
-    ap.add_argument("--snr", type=float, default=-3.0, help="Es/N0 in dB of the synthetic channel")
+    ap.add_argument("--snr", type=float, default=1.0, help="Es/N0 in dB of the synthetic channel")
     ap.add_argument("--max-iters", type=int, default=10)
     ap.add_argument("--kernel", type=int, default=0)
-    ap.add_argument("--fixed", action="store_true", help="no early exit: every frame runs max-iters updates")
+    ap.add_argument("--early-exit", action="store_true", help="the reference's syndrome check at the top of every "
+                    "iteration instead of exactly max-iters updates per frame")
+    ap.add_argument("--fixed", action="store_true", help="(default) exactly max-iters updates per frame")
     ap.add_argument("--cpu-sample", type=int, default=0, help="frames of the CPU baseline (0 = auto)")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--no-other", action="store_true")
+    ap.add_argument("--no-other", action="store_true", help="headline workload only (no bg1, no other)")
     args = ap.parse_args()
 
     import torch
@@ -150,72 +248,48 @@ def main():
             dist.init_process_group(backend)
     device = torch.device("cuda", local)
 
-    from ldpc_amd import codes, config, sweep
-    from ldpc_amd.decoder import Decoder
-
-    code = codes.load_packaged(args.code)
-    G = codes.load_packaged_generator(args.code)   # a k x n matrix, or a structured encoder for BG1
-    k_info = G.k if callable(G) else G.shape[0]
+    head = Runner(args.code, torch, dist, device, world, rank)
+    code = head.code
     if args.frames <= 0:
-        args.frames = 1 << 20 if code.n <= 1024 else max(1024, (3 << 30) // (4 * code.n) // 1024 * 1024)
-    cfg = config.PRESETS[args.rule].with_(max_iters=args.max_iters)
-    if args.fixed:
-        cfg = cfg.with_(early_exit=False)
-    compute = np.float64 if args.dtype == "f64" else np.float32
-    dec = Decoder(code)
-    batch = sweep.make_batch(code, G, args.frames, args.snr, cfg, seed=[7, rank], device=device)
-    kernel_name = [""]
-
-    def step():
-        kernel_name[0] = sweep.decode_batch(dec, batch, cfg, compute_dtype=compute, kernel=args.kernel)
-
-    wall, dev_ms = timed_steps(step, args.steps, args.warmup, torch, dist, world)
-    frames_total = args.frames * world * args.steps
-    value = frames_total * k_info / wall / 1e9
-
-    # error counters of the last step, summed over ranks: the one collective of the path
-    batch.counters.zero_()
-    sweep.count_errors(dec, batch)
-    sweep.allreduce_counters(batch.counters)
-    torch.cuda.synchronize()
-    stats = sweep.summarize(batch.counters.cpu().numpy(), code.n)
-
-    kernel_ms = dev_ms / args.steps
-    hbm_bytes = (5 * code.n + 5) * args.frames                  # f32 LLR in, u8 hard + i32 + u8 out
-    # iterations actually run: failures ran max_iters but report max-1; fixed mode reports max_iters
-    executed = stats["iterations"] + (0 if args.fixed else stats["not_converged"])
-    lds_bytes = lds_bytes_per_frame_iter(code, cfg.rule, 8 if args.dtype == "f64" else 4) * executed / world
-    roofline = {"bound": "hbm", "achieved": hbm_bytes / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "traffic": measured_traffic(args, args.frames), "kernel": kernel_name[0],
-                "kernel_ms": kernel_ms, "bytes_per_frame": 5 * code.n + 5}
-    roofline["frac"] = roofline["achieved"] / roofline["peak"]
-    lds = {"bound": "lds", "achieved": lds_bytes / (kernel_ms * 1e-3) / 1e9, "peak": LDS_PEAK_GBS,
-           "unit": "GB/s", "bytes_per_frame_iter": lds_bytes_per_frame_iter(code, cfg.rule, 8 if args.dtype == "f64" else 4)}
-    lds["frac"] = lds["achieved"] / lds["peak"]
-
+        args.frames = 1 << 20 if code.n <= 1024 else 16384
+    early = bool(args.early_exit)
+    res, batch, cfg = head.run(args.rule, args.dtype, args.snr, early, args.frames, args.steps, args.warmup,
+                               max_iters=args.max_iters, kernel=args.kernel, with_rooflines=True)
+    rule_text = {'R0': 'ldpc.py decoder', 'R1': 'bpsk.py decoder', 'LNMS': 'layered min-sum, build extension'}.get(args.rule, 'sum-product')
     out = {
-        "metric": "decoded info Gbit/s", "value": value, "unit": "Gbit/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
+        "metric": "decoded info Gbit/s", "value": res["value"], "unit": "Gbit/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
         "data": "synthetic",
-        "config": {"workload": f"{args.code} (n={code.n}, k={k_info}) x {args.frames} frames/launch/GPU, "
-                               f"rule {args.rule} ({ {'R0': 'ldpc.py decoder', 'R1': 'bpsk.py decoder', 'LNMS': 'layered min-sum, build extension'}.get(args.rule, 'sum-product') }), "
-                               f"max {args.max_iters} iterations, {'no early exit' if args.fixed else 'syndrome check per iteration'}, Es/N0 {args.snr} dB",
+        "config": {"workload": f"{args.code} (n={code.n}, k={head.k}) x {args.frames} frames/launch/GPU, "
+                               f"rule {args.rule} ({rule_text}), "
+                               f"{'at most' if early else 'exactly'} {args.max_iters} iterations"
+                               f"{' (syndrome check per iteration)' if early else ' per frame (no early exit)'}, Es/N0 {args.snr} dB",
                    "code": args.code, "frames_per_launch_per_gpu": args.frames, "rule": args.rule,
-                   "max_iters": args.max_iters, "early_exit": not args.fixed, "es_n0_db": args.snr,
-                   "llr_dtype": "f32", "kernel": kernel_name[0], "sharding": f"frames x{world}"},
-        "mean_iters": stats["mean_iters"], "fer": stats["fer"], "ber": stats["ber"],
-        "counters": {k: stats[k] for k in sweep.COUNTER_NAMES},
-        "roofline": roofline, "lds_roofline": lds,
+                   "max_iters": args.max_iters, "early_exit": early, "es_n0_db": args.snr,
+                   "llr_dtype": "f32", "kernel": res["kernel"], "sharding": f"frames x{world}"},
+        "mean_iters": res["mean_iters"], "fer": res["fer"], "ber": res["ber"], "counters": res["counters"],
+        "roofline": res["roofline"], "lds_roofline": res["lds_roofline"],
     }
-    vr = valu_roofline(args, executed / world, kernel_ms)
-    if vr:
-        out["valu_roofline"] = vr
-
+    if "valu_roofline" in res:
+        out["valu_roofline"] = res["valu_roofline"]
     if rank == 0 and world == 1 and not args.no_cpu:
-        out["cpu_baseline"] = cpu_baseline(code, cfg, batch, k_info, args)
-    if not args.no_other and args.code == "ccsds512":
-        out["other"] = other_workloads(code, G, dec, args, torch, dist, device, world, rank)
+        out["cpu_baseline"] = cpu_baseline(code, cfg, batch, head.k, args.dtype, 10.0, args.cpu_sample)
+        out["vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+    del batch
+
+    if not args.no_other and args.code == "ccsds512" and args.rule == "R0" and not early:
+        short = lambda r: {k: r[k] for k in ("value", "unit", "ms_per_step", "kernel", "mean_iters", "fer", "ber",
+                                             "es_n0_db", "early_exit", "frames_per_launch_per_gpu", "dtype")}
+        # the same kernel running the reference's loop (syndrome check at the top of every iteration)
+        r, b, _ = head.run(args.rule, args.dtype, 1.0, True, args.frames, 3, 1, seed=8)
+        out["operating_point"] = short(r)
+        del b
+        r, b, _ = head.run(args.rule, args.dtype, -3.0, True, args.frames, 3, 1, seed=8)
+        out["worst_case_early_exit"] = short(r)
+        del b
+        out["bg1"] = bg1_workloads(torch, dist, device, world, rank, args)
+        out["other"] = other_workloads(head, args, torch, dist, device, world, rank)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -223,64 +297,47 @@ def main():
         print(json.dumps(out))
 
 
-def cpu_baseline(code, cfg, batch, k_info, args):
-    """CPU restatement on a bounded sample of the same LLRs, all host threads; also checks that
-    the GPU's results for that sample are identical."""
-    from oracle import bp_oracle
-    bp_oracle.build_c_oracle()
-    threads = min(bp_oracle.c_max_threads(), len(os.sched_getaffinity(0)), 64)
-    if cfg.rule == 5:
-        decode = lambda x: bp_oracle.c_decode_lnms(code, cfg, x, nthreads=threads, use_float=args.dtype == "f32",
-                                                   want_posterior=False)
-    else:
-        decode = lambda x: bp_oracle.c_decode(code, cfg, x, nthreads=threads, want_posterior=False)
-    probe = (64 if code.n <= 1024 else 2) * threads
-    L = batch.llr[:probe].cpu().numpy().astype(np.float64)
-    t0 = time.perf_counter()
-    decode(L)
-    rate = probe / max(time.perf_counter() - t0, 1e-6)
-    sample = args.cpu_sample or int(min(batch.llr.shape[0], max(probe, rate * 15.0)))
-    L = batch.llr[:sample].cpu().numpy().astype(np.float64)
-    t0 = time.perf_counter()
-    hard, iters, conv, _ = decode(L)
-    dt = time.perf_counter() - t0
-    same = (np.array_equal(hard, batch.hard[:sample].cpu().numpy())
-            and np.array_equal(iters, batch.iters[:sample].cpu().numpy())
-            and np.array_equal(conv, batch.converged[:sample].cpu().numpy().astype(bool)))
-    return {"value": sample * k_info / dt / 1e9, "unit": "Gbit/s", "cores": threads, "kind": "port",
-            "sample": f"first {sample} frames of the same LLR batch, "
-                      f"{'float32' if (cfg.rule == 5 and args.dtype == 'f32') else 'float64'}, oracle/bp_oracle.c with "
-                      f"{threads} OpenMP threads, {dt:.1f} s",
-            "gpu_results_identical_on_sample": bool(same) if (args.dtype == "f64" or cfg.rule == 5) else None}
+def bg1_workloads(torch, dist, device, world, rank, args):
+    """NR BG1 Z=384 (build-authored table, ldpc_amd/nr_bg1.py) under row-layered min-sum: exactly 10
+    sweeps per frame in float32 and in float64, each with rooflines and (one GPU) a CPU baseline,
+    and the early-exit operating points of the float32 kernel."""
+    bg1 = Runner("nr_bg1_z384", torch, dist, device, world, rank)
+    frames = 16384
+    out = {"workload": f"nr_bg1_z384 (n={bg1.code.n}, k={bg1.k}; BG1 connectivity, synthetic shifts) x {frames} "
+                       f"frames/launch/GPU, rule LNMS (row-layered normalised min-sum, build extension), exactly 10 sweeps",
+           "metric": "decoded info Gbit/s"}
+    for dtype in ("f32", "f64"):
+        r, batch, cfg = bg1.run("LNMS", dtype, 0.0, False, frames, 5, 1, seed=9, with_rooflines=True)
+        r.pop("counters")
+        if rank == 0 and world == 1 and not args.no_cpu:
+            r["cpu_baseline"] = cpu_baseline(bg1.code, cfg, batch, bg1.k, dtype, 5.0)
+        out[dtype] = r
+        del batch
+    for label, snr in (("f32_early_exit_es_n0_-3dB", -3.0), ("f32_early_exit_es_n0_0dB", 0.0)):
+        r, batch, _ = bg1.run("LNMS", "f32", snr, True, frames, 3, 1, seed=9)
+        out[label] = {k: r[k] for k in ("value", "unit", "ms_per_step", "kernel", "mean_iters", "fer", "ber")}
+        del batch
+    return out
 
 
-def other_workloads(code, G, dec, args, torch, dist, device, world, rank):
+def other_workloads(head, args, torch, dist, device, world, rank):
     """Secondary workloads, 3 timed launches each on every rank; Gbit/s over all ranks, `frames`
     per launch and per GPU."""
-    from ldpc_amd import codes, config, sweep
-    from ldpc_amd.decoder import Decoder
+    from ldpc_amd import channel, config, sweep
     res = {}
 
-    def run(label, code_, G_, dec_, rule, dtype, snr, early, frames, k_info):
-        cfg = config.PRESETS[rule].with_(max_iters=args.max_iters, early_exit=early)
-        batch = sweep.make_batch(code_, G_, frames, snr, cfg, seed=[8, len(label), rank], device=device)
-        compute = np.float64 if dtype == "f64" else np.float32
-        wall, dev_ms = timed_steps(lambda: sweep.decode_batch(dec_, batch, cfg, compute_dtype=compute),
-                                   3, 1, torch, dist, world)
-        sweep.count_errors(dec_, batch)
-        sweep.allreduce_counters(batch.counters)
-        torch.cuda.synchronize()
-        st = sweep.summarize(batch.counters.cpu().numpy(), code_.n)
-        res[label] = {"gbit_s": frames * world * 3 * k_info / wall / 1e9, "mean_iters": st["mean_iters"],
-                      "fer": st["fer"], "ber": st["ber"], "frames": frames, "code": code_.name, "rule": rule,
-                      "dtype": dtype, "es_n0_db": snr, "early_exit": early}
+    def run(label, runner, rule, dtype, snr, early, frames):
+        r, b, _ = runner.run(rule, dtype, snr, early, frames, 3, 1, max_iters=args.max_iters, seed=8 + len(label))
+        res[label] = {"gbit_s": r["value"], "mean_iters": r["mean_iters"], "fer": r["fer"], "ber": r["ber"],
+                      "frames": frames, "code": runner.name, "rule": rule, "dtype": dtype, "es_n0_db": snr,
+                      "early_exit": early, "kernel": r["kernel"]}
+        del b
 
+    code = head.code
     frames = min(args.frames, 1 << 19)
-    k = G.shape[0]
     # the step in front of the decoder: BPSK + AWGN + LLRs generated on the device (n bytes in, 4n out)
-    from ldpc_amd import channel
     cfg0 = config.PRESETS["R0"]
-    probe = sweep.make_batch(code, G, frames, args.snr, cfg0, seed=[9, rank], device=device, native_noise=True)
+    probe = sweep.make_batch(code, head.G, frames, args.snr, cfg0, seed=[9, rank], device=device, native_noise=True)
     gen = lambda: channel.channel_llr_device(probe.ref.data_ptr(), code.n, frames, code.n, args.snr, cfg0, 7, 0,
                                              probe.llr.data_ptr(), np.float32,
                                              stream=torch.cuda.current_stream().cuda_stream)
@@ -289,33 +346,22 @@ def other_workloads(code, G, dec, args, torch, dist, device, world, rank):
                               "ms_per_launch": wall / 5 * 1e3, "bytes_per_frame": 5 * code.n}
     del probe
     for label, rule, dtype, snr, early in [
-        ("R0_f64_es_n0_1dB", "R0", "f64", 1.0, True),
-        ("R0_f32_worst_case", "R0", "f32", args.snr, True),
-        ("R1_f64_worst_case", "R1", "f64", args.snr, True),
+        ("R0_f32_fixed_10", "R0", "f32", 1.0, False),
+        ("R1_f64_fixed_10", "R1", "f64", 1.0, False),
+        ("R1_f32_fixed_10", "R1", "f32", 1.0, False),
         ("R1_f64_es_n0_1dB", "R1", "f64", 1.0, True),
-        ("R1_f32_worst_case", "R1", "f32", args.snr, True),
-        ("R0_f64_fixed_10", "R0", "f64", args.snr, False),
+        ("R3_f32_fixed_10", "R3", "f32", 1.0, False),
     ]:
-        run(label, code, G, dec, rule, dtype, snr, early, frames, k)
-    # the build-authored NR BG1 Z=384 code under row-layered min-sum (float; see ldpc_amd/nr_bg1.py)
-    bg1 = codes.load_packaged("nr_bg1_z384")
-    enc1 = codes.load_packaged_generator("nr_bg1_z384")
-    dec1 = Decoder(bg1)
-    run("BG1_Z384_LNMS_f32_fixed_10", bg1, enc1, dec1, "LNMS", "f32", -3.0, False, 16384, bg1.n - bg1.m)
-    run("BG1_Z384_LNMS_f32_es_n0_-3dB", bg1, enc1, dec1, "LNMS", "f32", -3.0, True, 16384, bg1.n - bg1.m)
-    run("BG1_Z384_LNMS_f32_es_n0_0dB", bg1, enc1, dec1, "LNMS", "f32", 0.0, True, 16384, bg1.n - bg1.m)
-    # sum-product (tanh rule of channel.py) on the headline code, and the flooding rules on the BG2-shaped
-    # 5G matrix of the reference (all-zero codeword: these rules are symmetric in the codeword)
-    run("R3_f32_fixed_10", code, G, dec, "R3", "f32", args.snr, False, frames // 4, k)
-    run("R3_f64_fixed_10", code, G, dec, "R3", "f64", args.snr, False, frames // 8, k)
-    bg2 = codes.load_packaged("nr_bg2_z40")
-    dec2 = Decoder(bg2)
-    k2 = bg2.n - bg2.m
+        run(label, head, rule, dtype, snr, early, frames if rule != "R3" else frames // 4)
+    run("R3_f64_fixed_10", head, "R3", "f64", 1.0, False, frames // 8)
+    # the flooding rules on the BG2-shaped 5G matrix of the reference (all-zero codeword: these rules are
+    # symmetric in the codeword)
+    bg2 = Runner("nr_bg2_z40", torch, dist, device, world, rank)
     for label, rule, dtype in [("BG2_Z40_R0_f64_fixed_10", "R0", "f64"), ("BG2_Z40_R0_f32_fixed_10", "R0", "f32"),
                                ("BG2_Z40_R1_f64_fixed_10", "R1", "f64"), ("BG2_Z40_R1_f32_fixed_10", "R1", "f32"),
                                ("BG2_Z40_R3_f32_fixed_10", "R3", "f32")]:
-        run(label, bg2, None, dec2, rule, dtype, -2.0, False, 32768, k2)
-    run("BG2_Z40_R1_f32_es_n0_-4dB", bg2, None, dec2, "R1", "f32", -4.0, True, 32768, k2)
+        run(label, bg2, rule, dtype, -2.0, False, 32768)
+    run("BG2_Z40_R1_f32_es_n0_-4dB", bg2, "R1", "f32", -4.0, True, 32768)
     return res
 
 

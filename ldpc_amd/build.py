@@ -42,6 +42,34 @@ HEADERS = ["bp_common.h", "bp_math.h", "spec_common.h", "spec_r1w_plan.h", os.pa
            os.path.join(ROOT, "include", "ldpc_amd.h")]
 
 
+#: source files each kernel family is built from (for stamping counter profiles)
+KERNEL_SOURCES = {"spec_lnms": ["decode_lnms.hip"], "spec_r0w": ["decode_spec_r1w.hip", "spec_r1w_plan.h"],
+                  "spec_r1w": ["decode_spec_r1w.hip", "spec_r1w_plan.h"], "spec_spaw": ["decode_spec_spaw.hip", "spec_r1w_plan.h"],
+                  "spec_spa": ["decode_spec_spa.hip"], "spec_r0": ["decode_spec.hip"], "spec_r1": ["decode_spec.hip"],
+                  "spec_oms": ["decode_spec.hip"], "qc_lnms": ["decode_qc_lnms.hip"], "qc_r0": ["decode_qc_r0.hip"],
+                  "qc": ["decode_qc.hip"], "csr": ["decode_csr.hip"]}
+
+
+def kernel_source_digest(kernel: str) -> str:
+    """First 16 hex digits of the SHA-256 over the sources the named kernel variant (as
+    ``ldpc_last_kernel`` reports it) is built from, plus the shared headers and the generated code
+    tables.  Counter profiles record it; a profile whose digest differs is from another kernel."""
+    import hashlib
+
+    files = None
+    for prefix in sorted(KERNEL_SOURCES, key=len, reverse=True):
+        if kernel.startswith(prefix):
+            files = KERNEL_SOURCES[prefix]
+            break
+    if files is None:
+        return ""
+    h = hashlib.sha256()
+    for f in list(files) + ["spec_common.h", "bp_common.h", "bp_math.h", os.path.join("gen", "codes_gen.h")]:
+        path = os.path.join(CSRC, f)
+        h.update(open(path, "rb").read() if os.path.exists(path) else b"")
+    return h.hexdigest()[:16]
+
+
 def _stale(target: str, deps) -> bool:
     if not os.path.exists(target):
         return True

@@ -11,10 +11,13 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from ldpc_amd.build import kernel_source_digest  # noqa: E402
 tag = sys.argv[1]
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(ROOT, "profiles")
 WORKLOADS = {"ccsds_r0_f64": "ccsds512/R0/f64/f32llr", "bg1_lnms_f32": "nr_bg1_z384/LNMS/f32/f32llr",
+             "bg1_lnms_f64": "nr_bg1_z384/LNMS/f64/f32llr",
              "bg2_R0_f64": "nr_bg2_z40/R0/f64/f32llr", "bg2_R0_f32": "nr_bg2_z40/R0/f32/f32llr",
              "bg2_R1_f32": "nr_bg2_z40/R1/f32/f32llr", "bg2_R3_f32": "nr_bg2_z40/R3/f32/f32llr"}
 # only the workloads this tag's run covered
@@ -62,7 +65,8 @@ for wl, key in WORKLOADS.items():
         "frames": frames, "FETCH_SIZE_KiB": vals["FETCH_SIZE"], "WRITE_SIZE_KiB": vals["WRITE_SIZE"],
         "hbm_bytes_corrected": total, "hbm_bytes_per_frame": total / frames,
         "algorithmic_bytes_per_frame": bench["roofline"]["bytes_per_frame"],
-        "early_exit": bench["config"]["early_exit"], "kernel": bench["config"]["kernel"]}
+        "early_exit": bench["config"]["early_exit"], "kernel": bench["config"]["kernel"],
+        "kernel_source_sha16": kernel_source_digest(bench["config"]["kernel"])}
 # instruction counters of the decode kernel (one more pass), per dispatch
 sq = {"note": "rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAVES SQ_WAVE_CYCLES "
               "SQ_BUSY_CU_CYCLES SQ_WAIT_ANY over the same bench command; sums over the device per dispatch of the "
@@ -83,6 +87,7 @@ for wl, key in WORKLOADS.items():
     executed = bench["counters"]["iterations"] + (0 if not bench["config"]["early_exit"] else bench["counters"]["not_converged"])
     mean.update({"frames": frames, "executed_frame_iterations": executed, "kernel": bench["config"]["kernel"],
                  "early_exit": bench["config"]["early_exit"],
+                 "kernel_source_sha16": kernel_source_digest(bench["config"]["kernel"]),
                  "valu_wave_instructions_per_frame_iteration": mean["SQ_INSTS_VALU"] / executed})
     sq["workloads"][key] = mean
 if sq["workloads"]:
