@@ -137,6 +137,25 @@ int32_t ldpc_decode_batch(ldpc_code *code, const ldpc_decode_config *cfg, const 
                           void *posterior_dev, void *stream);
 
 /*
+ * ldpc_decode_batch for callers that cannot allocate device memory (code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc).  NO counterpart in the reference.  Same
+ * arguments, same results.  The kernels that keep a frame's state in global memory (csr_global_*,
+ * qc_lnms_global_*: codes too large for LDS) take their per-workgroup slices from a file-scope
+ * device array of ldpc_noalloc_scratch_bytes() bytes (32 MiB, held on every GPU the library runs
+ * on until the process ends) instead of the handle's growable workspace, and start only as many
+ * workgroups as it holds slices for.  The call allocates and frees nothing.  A code whose state
+ * for one frame exceeds the array is refused with LDPC_ERR_UNSUPPORTED.  Every call on a GPU
+ * shares that GPU's array: calls that overlap in time on one GPU (different streams or threads)
+ * race; serialise them.
+ */
+int32_t ldpc_decode_batch_noalloc(ldpc_code *code, const ldpc_decode_config *cfg, const void *llr_dev,
+                                  int32_t llr_dtype, int32_t compute_dtype, int32_t kernel, int64_t frames,
+                                  uint8_t *hard_dev, int32_t *iters_dev, uint8_t *converged_dev,
+                                  void *posterior_dev, void *stream);
+/* size in bytes of the scratch array behind ldpc_decode_batch_noalloc */
+int64_t ldpc_noalloc_scratch_bytes(void);
+
+/*
  * Same, host buffers in and out (allocates device staging, copies, decodes, copies back,
  * synchronises).  This is what a one-frame-per-call caller such as the reference's drivers
  * (/root/reference/ldpc.py:392,654, bpsk.py:609,824) binds.

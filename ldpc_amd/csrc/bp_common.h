@@ -8,6 +8,12 @@
 namespace ldpc {
 
 constexpr int kMaxCheckDegree = 64;
+// bytes of the file-scope device array behind ldpc_decode_batch_noalloc (held per GPU until the process ends)
+#ifndef LDPC_NOALLOC_SCRATCH_BYTES
+#define LDPC_NOALLOC_SCRATCH_BYTES (32u << 20)
+#endif
+static_assert(true, "");
+constexpr int kUnused = 0;  // sign bits of one check are kept in one 64-bit mask
 
 // Edge lists on the device (all int32).
 struct CsrDev {

@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <utility>
 #include <vector>
@@ -56,6 +57,31 @@ struct ldpc_code {
         return workspaces.back().second;
     }
 };
+
+// Scratch of the allocation-free entry point: one array per device, shared by every call on that
+// device (it keeps the last call's contents; the kernels initialise what they read).
+constexpr size_t kNoallocScratchBytes = LDPC_NOALLOC_SCRATCH_BYTES;
+static __device__ __align__(256) unsigned char scratch[kNoallocScratchBytes];
+constexpr int kMaxDevices = 64;
+static std::mutex g_scratch_mutex;
+static void *g_scratch_ptr[kMaxDevices] = {};  // device address of `scratch` on each device, once looked up
+
+// Device address of this device's copy of `scratch` (the device must be current).
+static int noalloc_scratch(int device, Scratch *out)
+{
+    if (device < 0 || device >= kMaxDevices) return fail(LDPC_ERR_UNSUPPORTED, "device index %d beyond %d", device, kMaxDevices - 1);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void *ptr = nullptr;
+        hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !ptr) return fail(LDPC_ERR_HIP, "hipGetSymbolAddress(scratch): %s", hipGetErrorString(e));
+        g_scratch_ptr[device] = ptr;
+    }
+    out->ptr = g_scratch_ptr[device];
+    out->bytes = kNoallocScratchBytes;
+    out->fixed = true;
+    return LDPC_OK;
+}
 
 extern "C" const char *ldpc_last_error(void) { return g_err.c_str(); }
 extern "C" const char *ldpc_last_kernel(void) { return g_kernel; }
@@ -258,10 +284,11 @@ static int check_cfg(const ldpc_decode_config *cfg)
     return LDPC_OK;
 }
 
+// Shared body of ldpc_decode_batch and ldpc_decode_batch_noalloc; `noalloc` selects the scratch.
 static int decode_impl(ldpc_code *c, const ldpc_decode_config *cfg, const void *llr_dev,
                        int32_t llr_dtype, int32_t compute_dtype, int32_t kernel,
                        int64_t frames, uint8_t *hard_dev, int32_t *iters_dev,
-                       uint8_t *converged_dev, void *posterior_dev, void *stream)
+                       uint8_t *converged_dev, void *posterior_dev, void *stream, bool noalloc)
 {
     if (!c) return fail(LDPC_ERR_ARG, "code is NULL");
     if (int rc = check_cfg(cfg)) return rc;
@@ -275,7 +302,12 @@ static int decode_impl(ldpc_code *c, const ldpc_decode_config *cfg, const void *
 
     Launch io{llr_dev, llr_dtype, (long long)frames, hard_dev, iters_dev, converged_dev, posterior_dev,
               reinterpret_cast<hipStream_t>(stream)};
-    Scratch &ws = c->workspace_for(io.stream);
+    Scratch fixed_ws;
+    if (noalloc)
+        if (int rc = noalloc_scratch(c->device, &fixed_ws)) return rc;
+    Scratch &ws = noalloc ? fixed_ws : c->workspace_for(io.stream);
+    auto scratch_full = [&](hipError_t e) { return noalloc && e == hipErrorOutOfMemory; };
+    const char *too_big = "one frame's state exceeds the %zu bytes of scratch of the allocation-free entry point; use ldpc_decode_batch";
     // the loop-bound quirks exist only in the edge-list kernel
     const bool quirks = (cfg->rule == 0 && cfg->num_active_checks >= 0 && cfg->num_active_checks < c->m) ||
                         (cfg->rule != 0 && cfg->num_refresh_vars >= 0 && cfg->num_refresh_vars < c->n);
@@ -296,6 +328,7 @@ static int decode_impl(ldpc_code *c, const ldpc_decode_config *cfg, const void *
         if (kernel != LDPC_KERNEL_CSR && c->has_qc && !c->qc_pairs) {
             bool supported = false;
             hipError_t e = launch_qc_lnms(c->qc, *cfg, compute_dtype, io, c->num_cus, ws, &g_kernel, &supported);
+            if (scratch_full(e)) return fail(LDPC_ERR_UNSUPPORTED, too_big, kNoallocScratchBytes);
             if (e != hipSuccess) return fail(LDPC_ERR_HIP, "layered kernel launch: %s", hipGetErrorString(e));
             if (supported) return LDPC_OK;
         }
@@ -318,6 +351,7 @@ static int decode_impl(ldpc_code *c, const ldpc_decode_config *cfg, const void *
             return fail(LDPC_ERR_UNSUPPORTED, "circulant kernel cannot serve this code/dtype (LDS footprint or degree)");
     }
     hipError_t e = launch_csr(c->csr, *cfg, compute_dtype, io, c->num_cus, ws, &g_kernel);
+    if (scratch_full(e)) return fail(LDPC_ERR_UNSUPPORTED, too_big, kNoallocScratchBytes);
     if (e != hipSuccess) return fail(LDPC_ERR_HIP, "edge-list kernel launch: %s", hipGetErrorString(e));
     return LDPC_OK;
 }
@@ -328,8 +362,19 @@ extern "C" int32_t ldpc_decode_batch(ldpc_code *c, const ldpc_decode_config *cfg
                                      uint8_t *converged_dev, void *posterior_dev, void *stream)
 {
     return decode_impl(c, cfg, llr_dev, llr_dtype, compute_dtype, kernel, frames, hard_dev, iters_dev,
-                       converged_dev, posterior_dev, stream);
+                       converged_dev, posterior_dev, stream, false);
 }
+
+extern "C" int32_t ldpc_decode_batch_noalloc(ldpc_code *c, const ldpc_decode_config *cfg, const void *llr_dev,
+                                             int32_t llr_dtype, int32_t compute_dtype, int32_t kernel,
+                                             int64_t frames, uint8_t *hard_dev, int32_t *iters_dev,
+                                             uint8_t *converged_dev, void *posterior_dev, void *stream)
+{
+    return decode_impl(c, cfg, llr_dev, llr_dtype, compute_dtype, kernel, frames, hard_dev, iters_dev,
+                       converged_dev, posterior_dev, stream, true);
+}
+
+extern "C" int64_t ldpc_noalloc_scratch_bytes(void) { return (int64_t)kNoallocScratchBytes; }
 
 extern "C" int32_t ldpc_decode_batch_host(ldpc_code *c, const ldpc_decode_config *cfg, const void *llr,
                                           int32_t llr_dtype, int32_t compute_dtype, int32_t kernel,

@@ -98,9 +98,13 @@ class Decoder:
     # ------------------------------------------------------------------ device pointers
     def decode_device(self, llr_ptr: int, llr_dtype, frames: int, hard_ptr: int, iters_ptr: int,
                       conv_ptr: int, cfg: DecodeConfig, compute_dtype=np.float64,
-                      posterior_ptr: int = 0, stream: int = 0, kernel: int = _lib.KERNEL_AUTO) -> str:
+                      posterior_ptr: int = 0, stream: int = 0, kernel: int = _lib.KERNEL_AUTO,
+                      noalloc: bool = False) -> str:
+        """Enqueue one decode on device buffers.  ``noalloc`` goes through
+        ``ldpc_decode_batch_noalloc`` (no device allocation inside the call)."""
         ccfg = CDecodeConfig.from_config(cfg)
-        _lib.check(self._lib.ldpc_decode_batch(
+        entry = self._lib.ldpc_decode_batch_noalloc if noalloc else self._lib.ldpc_decode_batch
+        _lib.check(entry(
             self._h, ctypes.byref(ccfg), llr_ptr, _dtype_code(llr_dtype), _dtype_code(compute_dtype),
             kernel, int(frames), hard_ptr, iters_ptr, conv_ptr, posterior_ptr or None, stream or None))
         return _lib.last_kernel()
