@@ -45,6 +45,27 @@ extern "C" {
  * LDPC_ERR_UNSUPPORTED otherwise.
  */
 #define LDPC_RULE_LNMS 5
+/*
+ * Offset min-sum, flooding schedule.  NO counterpart in the reference (its only min-sum correction
+ * is the factor 0.75 of /root/reference/bpsk.py:233); a build extension that sits beside R1 and
+ * keeps every convention of it (LLR polarity, sign(0) := +1, ascending summation order, syndrome
+ * test at the top of each iteration, iteration count).  The check-to-variable magnitude is
+ *     max(scale * min_{k != i} |q_k| - offset, 0)
+ * evaluated in that order; scale = 1 gives the textbook offset rule, offset = 0 gives R1.
+ */
+#define LDPC_RULE_OMS 6
+
+/*
+ * Hard-decision bit flipping, /root/reference/ldpc.py:82-135 bitFlipDecode(codeword): bits are
+ * `0 if sample > 0 else 1`; at most max_iters (10, ldpc.py:102) passes, each preceded by the syndrome
+ * test; in a pass every check among the first num_active_checks rows (int(self.m), ldpc.py:113)
+ * sends each of its bits +1 when the parity of its OTHER bits is 1 and -1 otherwise, and a bit is
+ * flipped when its total exceeds half the degree of the LAST row visited (`len(Ej) / 2` after the
+ * loop, ldpc.py:130-132).  Only the sign of the input matters; integer arithmetic throughout.
+ * iters = passes made; converged = the syndrome test passed (no test after the last pass).
+ * posterior_dev must be NULL; compute_dtype is ignored.
+ */
+#define LDPC_RULE_BF 7
 
 #define LDPC_F32 0
 #define LDPC_F64 1
@@ -71,6 +92,7 @@ extern "C" {
  *                     the syndrome always uses every row.  -1 = all.
  *   num_refresh_vars  R1-R4: variables [0, k) refresh their variable-to-check messages
  *                     (range(self.n), bpsk.py:244); -1 = all.
+ *   offset            LDPC_RULE_OMS only: the offset beta (no counterpart in the reference).
  */
 typedef struct ldpc_decode_config {
     int32_t rule;
@@ -83,6 +105,7 @@ typedef struct ldpc_decode_config {
     double clip_tanh_arg;
     double clip_prod;
     double clip_post;
+    double offset;
 } ldpc_decode_config;
 
 typedef struct ldpc_code ldpc_code; /* opaque: compiled parity-check matrix resident on one device */
@@ -193,6 +216,46 @@ int32_t ldpc_channel_llr(const uint8_t *ref_dev, int64_t ref_stride, int64_t fra
                          double sigma2, double gain, int32_t plus_is_bit, int32_t prefix_len,
                          double prefix_llr, uint64_t seed, uint64_t first_frame, void *llr_dev,
                          int32_t llr_dtype, void *stream);
+
+/*
+ * ldpc_channel_llr under a Doppler-shifted carrier.  The reference holds no such signal path, only
+ * the time-scale factor 1 - v/c of a receiver moving at speed v through a medium of wave speed c
+ * (/root/reference/plotDoppler.py:5-6,14-16); the channel is this build's definition: the receiver
+ * follows the symbol timing, keeps the carrier phase acquired at the start of the frame, and
+ * integrates each symbol, so that
+ *   y_i = x_i * sinc(cfo) * cos(2 pi (cfo * (i + 1/2) + phase0)) + sqrt(sigma2) * N(0,1)
+ * with cfo = residual carrier offset in cycles per symbol (|cfo| < 1/2), e.g. (v/c) * carrier
+ * frequency / symbol rate * (1 - fraction compensated), and phase0 in cycles.  LLRs are formed as in
+ * ldpc_channel_llr (the receiver does not know about the rotation).  cfo = phase0 = 0 gives
+ * ldpc_channel_llr exactly.  Nothing pins these values but this build's oracle.
+ */
+int32_t ldpc_channel_llr_doppler(const uint8_t *ref_dev, int64_t ref_stride, int64_t frames, int32_t n,
+                                 double sigma2, double gain, int32_t plus_is_bit, int32_t prefix_len,
+                                 double prefix_llr, uint64_t seed, uint64_t first_frame,
+                                 double cfo_cycles_per_symbol, double phase0_cycles, void *llr_dev,
+                                 int32_t llr_dtype, void *stream);
+
+/*
+ * One batch that mixes frames of several codes (e.g. CCSDS and 5G frames of one link), decoded by
+ * one call: the batch is handed over as one segment per code, each with its own handle, buffers
+ * and stream; every segment is enqueued on its stream, so segments on different streams run side
+ * by side on the device.  The rule, arithmetic and kernel selector are shared.  No counterpart in
+ * the reference (it decodes one frame of one code per call, /root/reference/bpsk.py:824,
+ * channel.py:845).  Error statistics of all segments can be summed into one counter buffer by
+ * calling ldpc_count_errors per segment with the same counters_dev (it adds atomically).
+ */
+typedef struct ldpc_segment {
+    ldpc_code *code;
+    const void *llr_dev;   /* [frames, n of this code] */
+    int64_t frames;
+    uint8_t *hard_dev;
+    int32_t *iters_dev;
+    uint8_t *converged_dev;
+    void *posterior_dev;   /* or NULL */
+    void *stream;          /* hipStream_t, NULL = default stream */
+} ldpc_segment;
+int32_t ldpc_decode_segments(const ldpc_segment *segs, int32_t n_segs, const ldpc_decode_config *cfg,
+                             int32_t llr_dtype, int32_t compute_dtype, int32_t kernel);
 
 /* name of the kernel variant the last ldpc_decode_batch on this thread launched (for tests) */
 const char *ldpc_last_kernel(void);

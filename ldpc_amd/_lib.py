@@ -20,7 +20,16 @@ KERNEL_AUTO, KERNEL_CSR, KERNEL_QC = 0, 1, 2
 #: every symbol include/ldpc_amd.h declares
 SYMBOLS = ["ldpc_last_error", "ldpc_abi_version", "ldpc_device_count", "ldpc_code_create_csr",
            "ldpc_code_attach_qc", "ldpc_code_destroy", "ldpc_code_info", "ldpc_decode_batch",
-           "ldpc_decode_batch_host", "ldpc_decode_batch_noalloc", "ldpc_noalloc_scratch_bytes", "ldpc_count_errors", "ldpc_channel_llr", "ldpc_last_kernel"]
+           "ldpc_decode_batch_host", "ldpc_decode_batch_noalloc", "ldpc_noalloc_scratch_bytes", "ldpc_count_errors", "ldpc_channel_llr", "ldpc_channel_llr_doppler", "ldpc_decode_segments",
+           "ldpc_last_kernel"]
+
+
+class CSegment(ctypes.Structure):
+    """Binary image of ``ldpc_segment`` (include/ldpc_amd.h): one code's share of a mixed batch."""
+
+    _fields_ = [("code", ctypes.c_void_p), ("llr_dev", ctypes.c_void_p), ("frames", ctypes.c_int64),
+                ("hard_dev", ctypes.c_void_p), ("iters_dev", ctypes.c_void_p), ("converged_dev", ctypes.c_void_p),
+                ("posterior_dev", ctypes.c_void_p), ("stream", ctypes.c_void_p)]
 
 
 class LdpcError(RuntimeError):
@@ -93,6 +102,12 @@ def load() -> ctypes.CDLL:
     lib.ldpc_channel_llr.restype = i32
     lib.ldpc_channel_llr.argtypes = [vp, i64, i64, i32, ctypes.c_double, ctypes.c_double, i32, i32,
                                      ctypes.c_double, ctypes.c_uint64, ctypes.c_uint64, vp, i32, vp]
+    lib.ldpc_channel_llr_doppler.restype = i32
+    lib.ldpc_channel_llr_doppler.argtypes = [vp, i64, i64, i32, ctypes.c_double, ctypes.c_double, i32, i32,
+                                             ctypes.c_double, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_double,
+                                             ctypes.c_double, vp, i32, vp]
+    lib.ldpc_decode_segments.restype = i32
+    lib.ldpc_decode_segments.argtypes = [ctypes.POINTER(CSegment), i32, ctypes.POINTER(CDecodeConfig), i32, i32, i32]
     _lib = lib
     return lib
 

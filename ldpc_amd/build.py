@@ -30,15 +30,17 @@ UNITS += [("decode_spec_spa.o", "decode_spec_spa.hip", []),
           ("decode_lnms.o", "decode_lnms.hip", []),
           ("decode_spec_r1w_r1.o", "decode_spec_r1w.hip", ["-DLDPC_R1W_RULE=1"]),
           ("decode_spec_r1w_r0.o", "decode_spec_r1w.hip", ["-DLDPC_R1W_RULE=0"]),
+          ("decode_spec_r1w_r6.o", "decode_spec_r1w.hip", ["-DLDPC_R1W_RULE=6"]),
           ("decode_spec.o", "decode_spec.hip", [])]
-UNITS += [(f"decode_qc_r{k}.o", "decode_qc.hip", [f"-DLDPC_QC_RULE={k}"]) for k in range(1, 5)]
+UNITS += [(f"decode_qc_r{k}.o", "decode_qc.hip", [f"-DLDPC_QC_RULE={k}"]) for k in (1, 2, 3, 4, 6)]
 UNITS += [("decode_qc_r0.o", "decode_qc_r0.hip", []),
           ("decode_qc_lnms.o", "decode_qc_lnms.hip", []),
           ("decode_csr.o", "decode_csr.hip", []),
           ("ldpc_abi.o", "ldpc_abi.hip", []),
           ("count_errors.o", "count_errors.hip", []),
-          ("channel.o", "channel.hip", [])]
-HEADERS = ["bp_common.h", "bp_math.h", "spec_common.h", "spec_r1w_plan.h", os.path.join("gen", "codes_gen.h"),
+          ("channel.o", "channel.hip", []),
+          ("bitflip.o", "bitflip.hip", [])]
+HEADERS = ["bp_common.h", "extra_kernels.h", "bp_math.h", "spec_common.h", "spec_r1w_plan.h", os.path.join("gen", "codes_gen.h"),
            os.path.join(ROOT, "include", "ldpc_amd.h")]
 
 
@@ -46,7 +48,7 @@ HEADERS = ["bp_common.h", "bp_math.h", "spec_common.h", "spec_r1w_plan.h", os.pa
 KERNEL_SOURCES = {"spec_lnms": ["decode_lnms.hip"], "spec_r0w": ["decode_spec_r1w.hip", "spec_r1w_plan.h"],
                   "spec_r1w": ["decode_spec_r1w.hip", "spec_r1w_plan.h"], "spec_spaw": ["decode_spec_spaw.hip", "spec_r1w_plan.h"],
                   "spec_spa": ["decode_spec_spa.hip"], "spec_r0": ["decode_spec.hip"], "spec_r1": ["decode_spec.hip"],
-                  "spec_oms": ["decode_spec.hip"], "qc_lnms": ["decode_qc_lnms.hip"], "qc_r0": ["decode_qc_r0.hip"],
+                  "spec_oms": ["decode_spec.hip"], "spec_omsw": ["decode_spec_r1w.hip", "spec_r1w_plan.h"], "qc_lnms": ["decode_qc_lnms.hip"], "qc_r0": ["decode_qc_r0.hip"],
                   "qc": ["decode_qc.hip"], "csr": ["decode_csr.hip"]}
 
 

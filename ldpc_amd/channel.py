@@ -55,14 +55,35 @@ def llr_from_samples(y: np.ndarray, snr_db, cfg: DecodeConfig, compat_prefix: bo
     return L
 
 
+#: medium and platform of the reference's Doppler plot (/root/reference/plotDoppler.py:5-6): sound in
+#: water, 10 m/s of relative speed; its frequencies start at 12 kHz (plotDoppler.py:10)
+WAVE_SPEED, RELATIVE_SPEED, CARRIER_HZ = 1500.0, 10.0, 12000.0
+
+
+def doppler_scale(relative_speed: float = RELATIVE_SPEED, wave_speed: float = WAVE_SPEED) -> float:
+    """Time-scale factor 1 - v/c of the received signal (plotDoppler.py:14-16)."""
+    return 1.0 - relative_speed / wave_speed
+
+
+def doppler_cfo(symbol_rate: float, relative_speed: float = RELATIVE_SPEED, wave_speed: float = WAVE_SPEED,
+                carrier_hz: float = CARRIER_HZ, compensated: float = 0.0) -> float:
+    """Residual carrier offset in cycles per symbol that ``ldpc_channel_llr_doppler`` takes: the
+    carrier moves by (scale - 1) * carrier_hz; a receiver that removes the fraction ``compensated``
+    of it is left with the rest, expressed per symbol period."""
+    return (doppler_scale(relative_speed, wave_speed) - 1.0) * carrier_hz * (1.0 - compensated) / symbol_rate
+
+
 def channel_llr_device(ref_ptr: int, ref_stride: int, frames: int, n: int, snr_db: float, cfg: DecodeConfig,
                        seed: int, first_frame: int, llr_ptr: int, llr_dtype=np.float32, stream: int = 0,
-                       compat_prefix: bool = False, llr_scale_snr_db=None) -> None:
+                       compat_prefix: bool = False, llr_scale_snr_db=None, cfo: float = 0.0,
+                       phase0: float = 0.0) -> None:
     """The same on the device, for a whole batch (``ldpc_channel_llr``): BPSK with the polarity
     ``cfg`` assumes, noise of variance ``noise_variance(snr_db)``, LLR gain 2/sigma^2 (1/sigma^2 for
     R2) taken at ``llr_scale_snr_db`` if the receiver's SNR estimate differs from the channel's, and
     the rule's overwritten prefix when ``compat_prefix``.  ``ref_ptr`` = 0 sends the all-zero
-    codeword.  Frame f of the call gets the noise of absolute frame ``first_frame + f``."""
+    codeword.  Frame f of the call gets the noise of absolute frame ``first_frame + f``.  A non-zero
+    ``cfo`` (cycles per symbol, see ``doppler_cfo``) or ``phase0`` (cycles) selects the Doppler-shifted
+    channel ``ldpc_channel_llr_doppler``."""
     from . import _lib
     sigma2 = float(noise_variance(snr_db))
     sigma2_llr = sigma2 if llr_scale_snr_db is None else float(noise_variance(llr_scale_snr_db))
@@ -72,7 +93,12 @@ def channel_llr_device(ref_ptr: int, ref_stride: int, frames: int, n: int, snr_d
         plen, pval = PUNCTURE_PREFIX, 1e-9
     elif compat_prefix and cfg.rule in (RULE_R3, RULE_R4):
         plen, pval = PUNCTURE_PREFIX, 0.0
+    dt = 1 if np.dtype(llr_dtype) == np.float64 else 0
+    if cfo or phase0:
+        _lib.check(_lib.load().ldpc_channel_llr_doppler(
+            ref_ptr or None, int(ref_stride), int(frames), int(n), sigma2, gain, int(cfg.plus_is_bit == 1), plen, pval,
+            int(seed) & (2 ** 64 - 1), int(first_frame), float(cfo), float(phase0), llr_ptr, dt, stream or None))
+        return
     _lib.check(_lib.load().ldpc_channel_llr(ref_ptr or None, int(ref_stride), int(frames), int(n), sigma2, gain,
                                             int(cfg.plus_is_bit == 1), plen, pval, int(seed) & (2 ** 64 - 1),
-                                            int(first_frame), llr_ptr, 1 if np.dtype(llr_dtype) == np.float64 else 0,
-                                            stream or None))
+                                            int(first_frame), llr_ptr, dt, stream or None))

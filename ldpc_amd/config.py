@@ -9,8 +9,8 @@ from __future__ import annotations
 import ctypes
 from dataclasses import dataclass, replace
 
-RULE_R0, RULE_R1, RULE_R2, RULE_R3, RULE_R4, RULE_LNMS = range(6)
-RULE_NAMES = {"R0": 0, "R1": 1, "R2": 2, "R3": 3, "R4": 4, "LNMS": 5}
+RULE_R0, RULE_R1, RULE_R2, RULE_R3, RULE_R4, RULE_LNMS, RULE_OMS, RULE_BF = range(8)
+RULE_NAMES = {"R0": 0, "R1": 1, "R2": 2, "R3": 3, "R4": 4, "LNMS": 5, "OMS": 6, "BF": 7}
 
 
 @dataclass(frozen=True)
@@ -33,6 +33,8 @@ class DecodeConfig:
     clip_tanh_arg: float = 0.0
     clip_prod: float = 0.0
     clip_post: float = 0.0
+    #: OMS only: the offset beta in max(scale * min - offset, 0)
+    offset: float = 0.0
 
     def with_(self, **kw) -> "DecodeConfig":
         return replace(self, **kw)
@@ -60,7 +62,14 @@ R4 = DecodeConfig(rule=RULE_R4, max_iters=40, scale=1.0, clip_post=500.0)
 #: reference corresponds to it (see include/ldpc_amd.h)
 LNMS = DecodeConfig(rule=RULE_LNMS, max_iters=10, scale=0.75)
 
-PRESETS = {"R0": R0, "R1": R1, "R2": R2, "R3": R3, "R4": R4, "LNMS": LNMS}
+#: offset min-sum, flooding, R1's conventions and iteration cap, beta = 0.5 on LLRs 2y/sigma^2: build
+#: extension, nothing in the reference corresponds to it (see include/ldpc_amd.h)
+OMS = DecodeConfig(rule=RULE_OMS, max_iters=30, scale=1.0, offset=0.5)
+
+#: ldpc.py:82-135 — hard-decision bit flipping, 10 passes (ldpc.py:102)
+BF = DecodeConfig(rule=RULE_BF, max_iters=10, scale=1.0, float_syndrome0=False)
+
+PRESETS = {"R0": R0, "R1": R1, "R2": R2, "R3": R3, "R4": R4, "LNMS": LNMS, "OMS": OMS, "BF": BF}
 
 
 class CDecodeConfig(ctypes.Structure):
@@ -77,6 +86,7 @@ class CDecodeConfig(ctypes.Structure):
         ("clip_tanh_arg", ctypes.c_double),
         ("clip_prod", ctypes.c_double),
         ("clip_post", ctypes.c_double),
+        ("offset", ctypes.c_double),
     ]
 
     @classmethod
@@ -84,4 +94,4 @@ class CDecodeConfig(ctypes.Structure):
         return cls(int(cfg.rule), int(cfg.max_iters), int(bool(cfg.early_exit)),
                    int(bool(cfg.float_syndrome0)), int(cfg.num_active_checks),
                    int(cfg.num_refresh_vars), float(cfg.scale), float(cfg.clip_tanh_arg),
-                   float(cfg.clip_prod), float(cfg.clip_post))
+                   float(cfg.clip_prod), float(cfg.clip_post), float(cfg.offset))

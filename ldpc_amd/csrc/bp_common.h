@@ -47,7 +47,7 @@ struct QcDev {
 template <typename T>
 struct Cfg {
     int rule, max_iters, early_exit, float_syndrome0, num_active_checks, num_refresh_vars;
-    T scale, clip_tanh_arg, clip_prod, clip_post;
+    T scale, clip_tanh_arg, clip_prod, clip_post, offset;
 };
 
 struct Launch {
@@ -99,7 +99,7 @@ hipError_t launch_csr(const CsrDev &code, const ldpc_decode_config &cfg, int com
     hipError_t launch_qc_rule_##k(const QcDev &code, const ldpc_decode_config &cfg,                \
                                   int compute_dtype, const Launch &io, int num_cus,                \
                                   const char **kernel_name, bool *supported);
-LDPC_DECL_QC(0) LDPC_DECL_QC(1) LDPC_DECL_QC(2) LDPC_DECL_QC(3) LDPC_DECL_QC(4)
+LDPC_DECL_QC(0) LDPC_DECL_QC(1) LDPC_DECL_QC(2) LDPC_DECL_QC(3) LDPC_DECL_QC(4) LDPC_DECL_QC(6)
 #undef LDPC_DECL_QC
 // decode_spec.hip: kernels specialised at compile time for the packaged codes
 int spec_match(int Z, int mb, int nb, int Eb, const int *er, const int *ec, const int *es);
@@ -117,6 +117,8 @@ hipError_t launch_spec_r0w(int spec_id, const ldpc_decode_config &cfg, int compu
                            int num_cus, const char **kernel_name, bool *supported);
 hipError_t launch_spec_r1w(int spec_id, const ldpc_decode_config &cfg, int compute_dtype, const Launch &io,
                            int num_cus, const char **kernel_name, bool *supported);
+hipError_t launch_spec_omsw(int spec_id, const ldpc_decode_config &cfg, int compute_dtype, const Launch &io,
+                            int num_cus, const char **kernel_name, bool *supported);
 // decode_spec_spaw.hip: rules R2-R4 with several waves per frame group, one translation unit per rule
 #define LDPC_DECL_SPAW(k)                                                                          \
     hipError_t launch_spec_spaw_rule_##k(int spec_id, const ldpc_decode_config &cfg, int compute_dtype, \
@@ -133,7 +135,7 @@ hipError_t launch_count_errors(const uint8_t *hard, const uint8_t *ref, long lon
 // channel.hip
 hipError_t launch_channel_llr(const uint8_t *ref, long long ref_stride, long long frames, int n, double sigma2,
                               double gain, int plus_is_bit, int prefix_len, double prefix_llr,
-                              unsigned long long seed, unsigned long long first_frame, void *llr, int llr_dtype,
-                              hipStream_t stream);
+                              unsigned long long seed, unsigned long long first_frame, double cfo, double phase0,
+                              void *llr, int llr_dtype, hipStream_t stream);
 
 }  // namespace ldpc

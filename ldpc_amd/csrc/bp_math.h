@@ -189,6 +189,18 @@ __device__ inline T r1_message(const MinSumState<T> &s, int p, T scale) {
     return s.negative_excluding(p) ? -mag : mag;
 }
 
+// Offset min-sum magnitude (build extension, LDPC_RULE_OMS): max(scale * m - offset, 0), in that order
+template <typename T>
+__device__ inline T oms_magnitude(T m, T scale, T offset) {
+    const T t = scale * m - offset;
+    return t > (T)0 ? t : (T)0;
+}
+template <typename T>
+__device__ inline T oms_message(const MinSumState<T> &s, int p, T scale, T offset) {
+    T mag = oms_magnitude(s.magnitude_excluding(p), scale, offset);
+    return s.negative_excluding(p) ? -mag : mag;
+}
+
 // tanh(clip(q / 2, -c, c)) (bpsk.py:333; channel.py:471 has no clip, c <= 0)
 template <typename T>
 __device__ inline T spa_tanh_half(T q, T clip_arg) {
@@ -220,7 +232,7 @@ __device__ inline T phi_message(T phi_sum, bool negative) {
 // hard decision: R0 `0 if b < 0 else 1` (ldpc.py:198-201); R1-R4 `0 if b > 0 else 1` (bpsk.py:240-243)
 template <int RULE, typename T>
 __device__ inline unsigned hard_bit(T b) {
-    return RULE == 0 ? (b < (T)0 ? 0u : 1u) : (b > (T)0 ? 0u : 1u);
+    return RULE == 0 ? (b < (T)0 ? 0u : 1u) : (b > (T)0 ? 0u : 1u);  // the build's extra rules (5, 6) follow R1
 }
 
 }  // namespace ldpc

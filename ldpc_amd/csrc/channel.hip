@@ -8,6 +8,14 @@
 //   llr = gain * y            gain = 2 / sigma2 (ldpc.py:144) or 1 / sigma2 (bpsk.py:273)
 //   llr[i] = prefix_llr for i < prefix_len                 the hard-coded puncture prefix, bpsk.py:163
 //
+// Doppler variant (ldpc_channel_llr_doppler; build-defined, the reference only plots the scale factor
+// 1 - v/c, /root/reference/plotDoppler.py:14-16): the receiver follows the symbol timing but keeps the
+// carrier phase it acquired at the start of the frame, so symbol i arrives rotated by
+// 2 pi (cfo (i + 1/2) + phase0) with cfo = residual frequency offset in cycles per symbol, and an
+// integrate-and-dump matched filter loses the factor sinc(cfo) inside each symbol:
+//   y = x * sinc(cfo) * cos(2 pi (cfo (i + 1/2) + phase0)) + sqrt(sigma2) * N(0, 1)
+// The LLR formula stays that of an AWGN receiver (it does not know about the rotation).
+//
 // The reference draws its noise from numpy's global generator; nothing can reproduce that
 // stream, so the noise here is this build's own: Philox4x32-10 keyed by the caller's seed, counter
 // = (absolute frame index, position / 4), two Box-Muller pairs per counter value.  A frame's noise
@@ -50,8 +58,10 @@ template <typename TL>
 __global__ void __launch_bounds__(256)
 channel_llr_kernel(const uint8_t *__restrict__ ref, long long ref_stride, long long frames, int n,
                    float sigma, float gain, int plus_is_bit, int prefix_len, float prefix_llr,
-                   unsigned k0, unsigned k1, unsigned long long first_frame, TL *__restrict__ llr)
+                   unsigned k0, unsigned k1, unsigned long long first_frame, float cfo, float phase0, float amp,
+                   TL *__restrict__ llr)
 {
+    const bool doppler = cfo != 0.0f || phase0 != 0.0f;  // the same for every thread
     const int quads = (n + 3) / 4;
     const long long total = frames * quads;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -75,7 +85,12 @@ channel_llr_kernel(const uint8_t *__restrict__ ref, long long ref_stride, long l
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int pos = qd * 4 + j, b = (int)((bits >> (8 * j)) & 1u);
-            const float x = plus_is_bit ? (float)(2 * b - 1) : (float)(1 - 2 * b);
+            float x = plus_is_bit ? (float)(2 * b - 1) : (float)(1 - 2 * b);
+            if (doppler) {
+                float turns = cfo * ((float)pos + 0.5f) + phase0;
+                turns -= __builtin_floorf(turns);  // the hardware cosine takes turns, |argument| < 256
+                x *= amp * __builtin_amdgcn_cosf(turns);
+            }
             v[j] = pos < prefix_len ? prefix_llr : gain * (x + sigma * z[j]);
         }
         bool stored = false;
@@ -95,9 +110,11 @@ channel_llr_kernel(const uint8_t *__restrict__ ref, long long ref_stride, long l
 
 hipError_t launch_channel_llr(const uint8_t *ref, long long ref_stride, long long frames, int n, double sigma2,
                               double gain, int plus_is_bit, int prefix_len, double prefix_llr,
-                              unsigned long long seed, unsigned long long first_frame, void *llr, int llr_dtype,
-                              hipStream_t stream)
+                              unsigned long long seed, unsigned long long first_frame, double cfo, double phase0,
+                              void *llr, int llr_dtype, hipStream_t stream)
 {
+    const double pe = 3.14159265358979323846 * cfo;
+    const float amp = (float)(cfo == 0.0 ? 1.0 : sin(pe) / pe);  // sinc: loss of the integrate-and-dump filter
     const long long total = frames * ((n + 3) / 4);
     long long blocks = (total + 255) / 256;
     if (blocks > 16384) blocks = 16384;
@@ -107,11 +124,11 @@ hipError_t launch_channel_llr(const uint8_t *ref, long long ref_stride, long lon
     if (llr_dtype == LDPC_F64)
         hipLaunchKernelGGL(channel_llr_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, stream, ref, ref_stride,
                            frames, n, sigma, (float)gain, plus_is_bit, prefix_len, (float)prefix_llr, k0, k1,
-                           first_frame, reinterpret_cast<double *>(llr));
+                           first_frame, (float)cfo, (float)phase0, amp, reinterpret_cast<double *>(llr));
     else
         hipLaunchKernelGGL(channel_llr_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, stream, ref, ref_stride,
                            frames, n, sigma, (float)gain, plus_is_bit, prefix_len, (float)prefix_llr, k0, k1,
-                           first_frame, reinterpret_cast<float *>(llr));
+                           first_frame, (float)cfo, (float)phase0, amp, reinterpret_cast<float *>(llr));
     return hipGetLastError();
 }
 

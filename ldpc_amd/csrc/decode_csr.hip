@@ -96,14 +96,15 @@ __global__ void decode_csr_kernel(CsrDev c, Cfg<T> g, const TL *__restrict__ llr
             // ---- 2. check nodes
             for (int j = tid; j < (RULE == 0 ? mact : m); j += NT) {
                 const int e0 = c.row_ptr[j], d = c.row_ptr[j + 1] - e0;
-                if (RULE <= 1) {
+                if (RULE <= 1 || RULE == 6) {
                     if (d < 2) continue;  // ldpc.py:178, bpsk.py:216
                     MinSumState<T> s;
                     s.init();
                     for (int p = 0; p < d; ++p)
                         s.add(p, RULE == 0 ? post[c.col_idx[e0 + p]] : v2c[e0 + p]);
                     for (int p = 0; p < d; ++p)
-                        c2v[e0 + p] = RULE == 0 ? r0_message(s, p) : r1_message(s, p, g.scale);
+                        c2v[e0 + p] = RULE == 0 ? r0_message(s, p)
+                                      : (RULE == 6 ? oms_message(s, p, g.scale, g.offset) : r1_message(s, p, g.scale));
                 } else if (RULE == 2 || RULE == 3) {
                     // product of the other tanh values as prefix * suffix
                     for (int p = 0; p < d; ++p) c2v[e0 + p] = spa_tanh_half(v2c[e0 + p], g.clip_tanh_arg);
@@ -197,7 +198,7 @@ static Cfg<T> make_cfg(const ldpc_decode_config &c)
     g.float_syndrome0 = c.float_syndrome0; g.num_active_checks = c.num_active_checks;
     g.num_refresh_vars = c.num_refresh_vars;
     g.scale = (T)c.scale; g.clip_tanh_arg = (T)c.clip_tanh_arg; g.clip_prod = (T)c.clip_prod;
-    g.clip_post = (T)c.clip_post;
+    g.clip_post = (T)c.clip_post; g.offset = (T)c.offset;
     return g;
 }
 
@@ -253,6 +254,7 @@ static hipError_t launch_csr_rule(const CsrDev &code, const ldpc_decode_config &
         case 2: return launch_csr_t<2, T, TL>(code, cfg, io, num_cus, ws, name);
         case 3: return launch_csr_t<3, T, TL>(code, cfg, io, num_cus, ws, name);
         case 4: return launch_csr_t<4, T, TL>(code, cfg, io, num_cus, ws, name);
+        case 6: return launch_csr_t<6, T, TL>(code, cfg, io, num_cus, ws, name);
     }
     return hipErrorInvalidValue;
 }

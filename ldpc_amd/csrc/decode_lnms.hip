@@ -555,7 +555,7 @@ static hipError_t launch_lnms(const ldpc_decode_config &cfg, const Launch &io, i
     Cfg<T> g;
     g.rule = LDPC_RULE_LNMS; g.max_iters = cfg.max_iters; g.early_exit = cfg.early_exit;
     g.float_syndrome0 = 0; g.num_active_checks = -1; g.num_refresh_vars = -1;
-    g.scale = (T)cfg.scale; g.clip_tanh_arg = (T)0; g.clip_prod = (T)0; g.clip_post = (T)0;
+    g.scale = (T)cfg.scale; g.clip_tanh_arg = (T)0; g.clip_prod = (T)0; g.clip_post = (T)0; g.offset = (T)0;
     auto k = lnms_kernel<C, T, TL, F, CF::RL, CF::WPE>;
     static int static_lds = -1;  // the kernel addresses LDS from 0: it must own the whole segment
     if (static_lds < 0) {

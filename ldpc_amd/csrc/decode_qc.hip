@@ -108,7 +108,7 @@ __device__ __forceinline__ int check_row(const QcCtx &x, const Cfg<T> &g, const_
     }
     if (!update) return bad;
 
-    if (RULE <= 1) {
+    if (RULE <= 1 || RULE == 6) {
         if (D >= 2) {  // ldpc.py:178, bpsk.py:216
             MinSumState<T> st;
             st.init();
@@ -116,7 +116,8 @@ __device__ __forceinline__ int check_row(const QcCtx &x, const Cfg<T> &g, const_
             for (int p = 0; p < D; ++p) st.add(p, v[p]);
 #pragma unroll
             for (int p = 0; p < D; ++p)
-                msg[(e0 + p) * x.FZ + x.tid] = RULE == 0 ? r0_message(st, p) : r1_message(st, p, g.scale);
+                msg[(e0 + p) * x.FZ + x.tid] = RULE == 0 ? r0_message(st, p)
+                                               : (RULE == 6 ? oms_message(st, p, g.scale, g.offset) : r1_message(st, p, g.scale));
         } else {
             msg[e0 * x.FZ + x.tid] = (T)0;
         }
@@ -391,7 +392,7 @@ static Cfg<T> make_cfg(const ldpc_decode_config &c)
     g.float_syndrome0 = c.float_syndrome0; g.num_active_checks = c.num_active_checks;
     g.num_refresh_vars = c.num_refresh_vars;
     g.scale = (T)c.scale; g.clip_tanh_arg = (T)c.clip_tanh_arg; g.clip_prod = (T)c.clip_prod;
-    g.clip_post = (T)c.clip_post;
+    g.clip_post = (T)c.clip_post; g.offset = (T)c.offset;
     return g;
 }
 
@@ -485,7 +486,7 @@ static hipError_t launch_qc_rule(const QcDev &q, const ldpc_decode_config &cfg, 
 }
 
 #ifndef LDPC_QC_RULE
-#error "compile with -DLDPC_QC_RULE=<0..4>: one translation unit per rule"
+#error "compile with -DLDPC_QC_RULE=<1..4 or 6>: one translation unit per rule"
 #endif
 
 #define LDPC_CAT2(a, b) a##b

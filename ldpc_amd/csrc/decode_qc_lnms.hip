@@ -227,7 +227,7 @@ static hipError_t launch_qc_lnms_t(const QcDev &code, const ldpc_decode_config &
     Cfg<T> g;
     g.rule = LDPC_RULE_LNMS; g.max_iters = cfg.max_iters; g.early_exit = cfg.early_exit;
     g.float_syndrome0 = 0; g.num_active_checks = -1; g.num_refresh_vars = -1;
-    g.scale = (T)cfg.scale; g.clip_tanh_arg = (T)0; g.clip_prod = (T)0; g.clip_post = (T)0;
+    g.scale = (T)cfg.scale; g.clip_tanh_arg = (T)0; g.clip_prod = (T)0; g.clip_post = (T)0; g.offset = (T)0;
     auto launch = [&](auto k) -> hipError_t {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -338,7 +338,7 @@ static hipError_t launch_r0_t(const QcDev &q, const ldpc_decode_config &cfg, con
     Cfg<T> g;
     g.rule = 0; g.max_iters = cfg.max_iters; g.early_exit = cfg.early_exit;
     g.float_syndrome0 = cfg.float_syndrome0; g.num_active_checks = -1; g.num_refresh_vars = -1;
-    g.scale = (T)cfg.scale; g.clip_tanh_arg = (T)0; g.clip_prod = (T)0; g.clip_post = (T)0;
+    g.scale = (T)cfg.scale; g.clip_tanh_arg = (T)0; g.clip_prod = (T)0; g.clip_post = (T)0; g.offset = (T)0;
     auto k = decode_qc_r0_kernel<T, TL, DC, DV>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -237,7 +237,7 @@ struct R1Layout {
     static constexpr bool QREG = C::EB * (int)sizeof(T) / 4 <= 72;  // own messages in registers
 };
 
-template <class C, typename T, typename TL, int F>
+template <class C, typename T, typename TL, int F, bool OMS>  // OMS: the offset rule (LDPC_RULE_OMS) instead of R1's
 __global__ void __launch_bounds__(64) LDPC_SPEC_OCC
 spec_r1_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__restrict__ hard_out,
                int *__restrict__ iters_out, uint8_t *__restrict__ conv_out, T *__restrict__ post_out)
@@ -337,7 +337,11 @@ spec_r1_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *
                         off[k] = rot_bwd<Z, SP, s>(zp);
                         const Pair c = *reinterpret_cast<const Pair *>(cs_b + br * Z * SP + off[k]);
                         const T sel = t_abs(qo) == t_abs(c.x) ? c.y : c.x;
-                        r[k] = SNum<T>::flip_sign(g.scale * sel, SNum<T>::sign_word(qo) & 0x80000000u);
+                        // sel carries the sign parity of the check in its sign bit
+                        const T mag = OMS ? SNum<T>::flip_sign(oms_magnitude(t_abs(sel), g.scale, g.offset),
+                                                               SNum<T>::sign_word(sel) & 0x80000000u)
+                                          : g.scale * sel;
+                        r[k] = SNum<T>::flip_sign(mag, SNum<T>::sign_word(qo) & 0x80000000u);
                     });
                     bool sw[D > 0 ? D : 1];
                     static_for<0, (D > 0 ? D - 1 : 0)>([&](auto k) {
@@ -397,7 +401,7 @@ static hipError_t launch_spec_r0(const ldpc_decode_config &cfg, const Launch &io
     Cfg<T> g;
     g.rule = 0; g.max_iters = cfg.max_iters; g.early_exit = cfg.early_exit;
     g.float_syndrome0 = cfg.float_syndrome0; g.num_active_checks = -1; g.num_refresh_vars = -1;
-    g.scale = (T)cfg.scale; g.clip_tanh_arg = (T)0; g.clip_prod = (T)0; g.clip_post = (T)0;
+    g.scale = (T)cfg.scale; g.clip_tanh_arg = (T)0; g.clip_prod = (T)0; g.clip_post = (T)0; g.offset = (T)0;
     auto k = spec_r0_kernel<C, T, TL, F>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LY::LDS_BYTES);
@@ -417,28 +421,28 @@ static hipError_t launch_spec_r0(const ldpc_decode_config &cfg, const Launch &io
     return hipGetLastError();
 }
 
-template <class C, typename T, typename TL, int F>
+template <class C, typename T, typename TL, int F, bool OMS = false>
 static hipError_t launch_spec_r1(const ldpc_decode_config &cfg, const Launch &io, int num_cus, const char **name)
 {
     typedef R1Layout<C, T, F> LY;
     Cfg<T> g;
-    g.rule = 1; g.max_iters = cfg.max_iters; g.early_exit = cfg.early_exit;
+    g.rule = cfg.rule; g.max_iters = cfg.max_iters; g.early_exit = cfg.early_exit;
     g.float_syndrome0 = 0; g.num_active_checks = -1; g.num_refresh_vars = -1;
-    g.scale = (T)cfg.scale; g.clip_tanh_arg = (T)0; g.clip_prod = (T)0; g.clip_post = (T)0;
+    g.scale = (T)cfg.scale; g.clip_tanh_arg = (T)0; g.clip_prod = (T)0; g.clip_post = (T)0; g.offset = (T)cfg.offset;
     size_t per_cu = (160 * 1024) / LY::LDS_BYTES;
     if (per_cu > 32) per_cu = 32;
     const long long groups = (io.frames + F - 1) / F;
     long long grid = (long long)num_cus * (long long)per_cu * 2;
     if (grid > groups) grid = groups;
     if (grid < 1) grid = 1;
-    auto k = spec_r1_kernel<C, T, TL, F>;
+    auto k = spec_r1_kernel<C, T, TL, F, OMS>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LY::LDS_BYTES);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(64), LY::LDS_BYTES, io.stream, g,
                        reinterpret_cast<const TL *>(io.llr), io.frames, io.hard, io.iters, io.converged,
                        reinterpret_cast<T *>(io.posterior));
-    *name = sizeof(T) == 8 ? "spec_r1_f64" : "spec_r1_f32";
+    *name = OMS ? (sizeof(T) == 8 ? "spec_oms_f64" : "spec_oms_f32") : (sizeof(T) == 8 ? "spec_r1_f64" : "spec_r1_f32");
     return hipGetLastError();
 }
 
@@ -463,6 +467,13 @@ static hipError_t launch_spec_code(const ldpc_decode_config &cfg, int compute_dt
                 return launch_spec_r1<C, double, float, F>(cfg, io, num_cus, name);
             }
             if (io.llr_dtype == LDPC_F32) return launch_spec_r1<C, float, float, F>(cfg, io, num_cus, name);
+        }
+        if (cfg.rule == LDPC_RULE_OMS) {
+            if (compute_dtype == LDPC_F64) {
+                if (io.llr_dtype == LDPC_F64) return launch_spec_r1<C, double, double, F, true>(cfg, io, num_cus, name);
+                return launch_spec_r1<C, double, float, F, true>(cfg, io, num_cus, name);
+            }
+            if (io.llr_dtype == LDPC_F32) return launch_spec_r1<C, float, float, F, true>(cfg, io, num_cus, name);
         }
     }
     *supported = false;
@@ -492,9 +503,10 @@ hipError_t launch_spec(int spec_id, const ldpc_decode_config &cfg, int compute_d
         if (cfg.rule == 3) return launch_spec_spaw_rule_3(spec_id, cfg, compute_dtype, io, num_cus, name, supported);
         return launch_spec_spaw_rule_4(spec_id, cfg, compute_dtype, io, num_cus, name, supported);
     }
-    if (cfg.rule == 0 || cfg.rule == 1) {  // decode_spec_r1w.hip: codes too large for one wave per workgroup
-        hipError_t e = cfg.rule == 0 ? launch_spec_r0w(spec_id, cfg, compute_dtype, io, num_cus, name, supported)
-                                     : launch_spec_r1w(spec_id, cfg, compute_dtype, io, num_cus, name, supported);
+    if (cfg.rule == 0 || cfg.rule == 1 || cfg.rule == LDPC_RULE_OMS) {  // decode_spec_r1w.hip: codes too large for one wave per workgroup
+        hipError_t e = cfg.rule == 0   ? launch_spec_r0w(spec_id, cfg, compute_dtype, io, num_cus, name, supported)
+                       : cfg.rule == 1 ? launch_spec_r1w(spec_id, cfg, compute_dtype, io, num_cus, name, supported)
+                                       : launch_spec_omsw(spec_id, cfg, compute_dtype, io, num_cus, name, supported);
         if (e != hipSuccess || *supported) return e;
     }
     int id = 0;

@@ -31,7 +31,7 @@ struct R1wLayout {
     static constexpr int LDS_BYTES = FLAG_OFF + 64;
 };
 
-template <class C, typename T, typename TL, int F, int W>
+template <class C, typename T, typename TL, int F, int W, bool OMS>  // OMS: the offset rule (LDPC_RULE_OMS) instead of R1's
 __global__ void __launch_bounds__(64 * W * ((F * C::Z + 63) / 64))
 spec_r1w_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__restrict__ hard_out,
                 int *__restrict__ iters_out, uint8_t *__restrict__ conv_out, T *__restrict__ post_out)
@@ -151,7 +151,9 @@ spec_r1w_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t 
                                     off[k] = rot_bwd<Z, SP, s>(zp);
                                     const Pair c = *reinterpret_cast<const Pair *>(cs_b + br * Z * SP + off[k]);
                                     const T sel = t_abs(qo) == t_abs(c.x) ? c.y : c.x;
-                                    r[k] = SNum<T>::flip_sign(g.scale * sel, SNum<T>::sign_word(qo) & 0x80000000u);
+                                    r[k] = SNum<T>::flip_sign(OMS ? SNum<T>::flip_sign(oms_magnitude(t_abs(sel), g.scale, g.offset), SNum<T>::sign_word(sel) & 0x80000000u)
+                                                                               : g.scale * sel,
+                                                                           SNum<T>::sign_word(qo) & 0x80000000u);
                                 });
                                 bool sw[D > 0 ? D : 1];
                                 static_for<0, (D > 0 ? D - 1 : 0)>([&](auto k) {
@@ -217,7 +219,7 @@ spec_r1w_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t 
 // Every wave tracks all slots' iteration counters and queue positions as uniform values (they
 // follow from the syndrome flags every wave reads), so the loop ends for all waves together when
 // the last queue is empty.  Same arithmetic as spec_r1w_kernel; g.early_exit != 0, max_iters >= 1.
-template <class C, typename T, typename TL, int F, int W>
+template <class C, typename T, typename TL, int F, int W, bool OMS>  // OMS: the offset rule (LDPC_RULE_OMS) instead of R1's
 __global__ void __launch_bounds__(64 * W * ((F * C::Z + 63) / 64))
 spec_r1w_slots_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__restrict__ hard_out,
                       int *__restrict__ iters_out, uint8_t *__restrict__ conv_out, T *__restrict__ post_out)
@@ -338,7 +340,9 @@ spec_r1w_slots_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, ui
                                 off[k] = rot_bwd<Z, SP, s>(zp);
                                 const Pair c = *reinterpret_cast<const Pair *>(cs_b + br * Z * SP + off[k]);
                                 const T sel = t_abs(qo) == t_abs(c.x) ? c.y : c.x;
-                                r[k] = SNum<T>::flip_sign(g.scale * sel, SNum<T>::sign_word(qo) & 0x80000000u);
+                                r[k] = SNum<T>::flip_sign(OMS ? SNum<T>::flip_sign(oms_magnitude(t_abs(sel), g.scale, g.offset), SNum<T>::sign_word(sel) & 0x80000000u)
+                                                                               : g.scale * sel,
+                                                                           SNum<T>::sign_word(qo) & 0x80000000u);
                             });
                             bool sw[D > 0 ? D : 1];
                             static_for<0, (D > 0 ? D - 1 : 0)>([&](auto k) {
@@ -597,18 +601,23 @@ constexpr int packed_slots()
 }
 
 // ------------------------------------------------------------------------------------------ host
+#ifndef LDPC_R1W_RULE
+#error "compile with -DLDPC_R1W_RULE=0, 1 or 6"
+#endif
+constexpr bool kOms = LDPC_R1W_RULE == 6;  // this translation unit builds the offset rule instead of R1
+
 template <class C, typename T, typename TL, int F, int W>
 static hipError_t launch_r1w(const ldpc_decode_config &cfg, const Launch &io, int num_cus, const char **name)
 {
     typedef R1wLayout<C, T, F> LY;
     constexpr int G = (LY::LANES + 63) / 64;
     Cfg<T> g;
-    g.rule = 1; g.max_iters = cfg.max_iters; g.early_exit = cfg.early_exit;
+    g.rule = cfg.rule; g.max_iters = cfg.max_iters; g.early_exit = cfg.early_exit;
     g.float_syndrome0 = 0; g.num_active_checks = -1; g.num_refresh_vars = -1;
-    g.scale = (T)cfg.scale; g.clip_tanh_arg = (T)0; g.clip_prod = (T)0; g.clip_post = (T)0;
-    auto k = spec_r1w_kernel<C, T, TL, F, W>;
+    g.scale = (T)cfg.scale; g.clip_tanh_arg = (T)0; g.clip_prod = (T)0; g.clip_post = (T)0; g.offset = (T)cfg.offset;
+    auto k = spec_r1w_kernel<C, T, TL, F, W, kOms>;
     if constexpr (F > 1) {  // early exit with several slots: every slot runs its own queue of frames
-        if (cfg.early_exit && cfg.max_iters >= 1) k = spec_r1w_slots_kernel<C, T, TL, F, W>;
+        if (cfg.early_exit && cfg.max_iters >= 1) k = spec_r1w_slots_kernel<C, T, TL, F, W, kOms>;
     }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LY::LDS_BYTES);
@@ -624,7 +633,7 @@ static hipError_t launch_r1w(const ldpc_decode_config &cfg, const Launch &io, in
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(64 * W * G), LY::LDS_BYTES, io.stream, g,
                        reinterpret_cast<const TL *>(io.llr), io.frames, io.hard, io.iters, io.converged,
                        reinterpret_cast<T *>(io.posterior));
-    *name = sizeof(T) == 8 ? "spec_r1w_f64" : "spec_r1w_f32";
+    *name = kOms ? (sizeof(T) == 8 ? "spec_omsw_f64" : "spec_omsw_f32") : (sizeof(T) == 8 ? "spec_r1w_f64" : "spec_r1w_f32");
     return hipGetLastError();
 }
 
@@ -673,7 +682,7 @@ static hipError_t launch_r0w(const ldpc_decode_config &cfg, const Launch &io, in
     Cfg<T> g;
     g.rule = 0; g.max_iters = cfg.max_iters; g.early_exit = cfg.early_exit;
     g.float_syndrome0 = cfg.float_syndrome0; g.num_active_checks = -1; g.num_refresh_vars = -1;
-    g.scale = (T)cfg.scale; g.clip_tanh_arg = (T)0; g.clip_prod = (T)0; g.clip_post = (T)0;
+    g.scale = (T)cfg.scale; g.clip_tanh_arg = (T)0; g.clip_prod = (T)0; g.clip_post = (T)0; g.offset = (T)0;
     auto k = spec_r0w_kernel<C, T, TL, F, W>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LY::LDS_BYTES);
@@ -724,14 +733,14 @@ static hipError_t launch_r0w_code(const ldpc_decode_config &cfg, int compute_dty
     return hipSuccess;
 }
 
-// One translation unit per rule (-DLDPC_R1W_RULE=0 or 1) so that the two compile side by side;
+// One translation unit per rule (-DLDPC_R1W_RULE=0, 1 or 6) so that they compile side by side;
 // templates the unit does not launch are never instantiated.
-#ifndef LDPC_R1W_RULE
-#error "compile with -DLDPC_R1W_RULE=0 or 1"
-#endif
 #if LDPC_R1W_RULE == 0
 hipError_t launch_spec_r0w(int spec_id, const ldpc_decode_config &cfg, int compute_dtype, const Launch &io,
                            int num_cus, const char **name, bool *supported)
+#elif LDPC_R1W_RULE == 6
+hipError_t launch_spec_omsw(int spec_id, const ldpc_decode_config &cfg, int compute_dtype, const Launch &io,
+                            int num_cus, const char **name, bool *supported)
 #else
 hipError_t launch_spec_r1w(int spec_id, const ldpc_decode_config &cfg, int compute_dtype, const Launch &io,
                            int num_cus, const char **name, bool *supported)

@@ -188,7 +188,7 @@ static hipError_t launch_spa(const ldpc_decode_config &cfg, const Launch &io, in
     g.rule = RULE; g.max_iters = cfg.max_iters; g.early_exit = cfg.early_exit;
     g.float_syndrome0 = 0; g.num_active_checks = -1; g.num_refresh_vars = -1;
     g.scale = (T)cfg.scale; g.clip_tanh_arg = (T)cfg.clip_tanh_arg; g.clip_prod = (T)cfg.clip_prod;
-    g.clip_post = (T)cfg.clip_post;
+    g.clip_post = (T)cfg.clip_post; g.offset = (T)cfg.offset;
     auto k = spec_spa_kernel<RULE, C, T, TL, F>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LY::LDS_BYTES);

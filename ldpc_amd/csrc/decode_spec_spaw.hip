@@ -462,7 +462,7 @@ static hipError_t launch_spaw(const ldpc_decode_config &cfg, const Launch &io, i
     g.rule = RULE; g.max_iters = cfg.max_iters; g.early_exit = cfg.early_exit;
     g.float_syndrome0 = 0; g.num_active_checks = -1; g.num_refresh_vars = -1;
     g.scale = (T)cfg.scale; g.clip_tanh_arg = (T)cfg.clip_tanh_arg; g.clip_prod = (T)cfg.clip_prod;
-    g.clip_post = (T)cfg.clip_post;
+    g.clip_post = (T)cfg.clip_post; g.offset = (T)cfg.offset;
     auto k = spec_spaw_kernel<RULE, C, T, TL, F, W>;
     if constexpr (F > 1) {  // early exit with several slots: every slot runs its own queue of frames
         if (cfg.early_exit && cfg.max_iters >= 1) k = spec_spaw_slots_kernel<RULE, C, T, TL, F, W>;

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "bp_common.h"
+#include "extra_kernels.h"
 
 using namespace ldpc;
 
@@ -85,7 +86,7 @@ static int noalloc_scratch(int device, Scratch *out)
 
 extern "C" const char *ldpc_last_error(void) { return g_err.c_str(); }
 extern "C" const char *ldpc_last_kernel(void) { return g_kernel; }
-extern "C" int32_t ldpc_abi_version(void) { return 1; }
+extern "C" int32_t ldpc_abi_version(void) { return 2; }
 
 extern "C" int32_t ldpc_device_count(int32_t *count)
 {
@@ -277,7 +278,8 @@ extern "C" int32_t ldpc_code_info(const ldpc_code *c, int32_t *m, int32_t *n, in
 static int check_cfg(const ldpc_decode_config *cfg)
 {
     if (!cfg) return fail(LDPC_ERR_ARG, "cfg is NULL");
-    if (cfg->rule < 0 || cfg->rule > LDPC_RULE_LNMS) return fail(LDPC_ERR_ARG, "rule %d is not one of R0..R4 or LNMS", cfg->rule);
+    if (cfg->rule < 0 || cfg->rule > LDPC_RULE_BF) return fail(LDPC_ERR_ARG, "rule %d is not one of R0..R4, LNMS, OMS or BF", cfg->rule);
+    if (cfg->rule == LDPC_RULE_OMS && !(cfg->offset >= 0.0)) return fail(LDPC_ERR_ARG, "offset must not be negative");
     if (cfg->max_iters < 1 || cfg->max_iters > 100000) return fail(LDPC_ERR_ARG, "max_iters %d out of range", cfg->max_iters);
     if ((cfg->rule == 2 || cfg->rule == 3) && !(cfg->clip_prod > 0.0 && cfg->clip_prod <= 1.0))
         return fail(LDPC_ERR_ARG, "clip_prod must lie in (0, 1] for the tanh rules");
@@ -308,6 +310,14 @@ static int decode_impl(ldpc_code *c, const ldpc_decode_config *cfg, const void *
     Scratch &ws = noalloc ? fixed_ws : c->workspace_for(io.stream);
     auto scratch_full = [&](hipError_t e) { return noalloc && e == hipErrorOutOfMemory; };
     const char *too_big = "one frame's state exceeds the %zu bytes of scratch of the allocation-free entry point; use ldpc_decode_batch";
+    if (cfg->rule == LDPC_RULE_BF) {  // hard-decision bit flipping: its own kernel, any matrix
+        if (posterior_dev) return fail(LDPC_ERR_UNSUPPORTED, "bit flipping has no posteriors: pass posterior_dev = NULL");
+        bool supported = false;
+        hipError_t e = launch_bitflip(c->csr, cfg->max_iters, cfg->num_active_checks, io, c->num_cus, &g_kernel, &supported);
+        if (e != hipSuccess) return fail(LDPC_ERR_HIP, "bit-flipping kernel launch: %s", hipGetErrorString(e));
+        if (!supported) return fail(LDPC_ERR_UNSUPPORTED, "bit flipping keeps 5 n + m bytes of a frame in LDS: the matrix is too large");
+        return LDPC_OK;
+    }
     // the loop-bound quirks exist only in the edge-list kernel
     const bool quirks = (cfg->rule == 0 && cfg->num_active_checks >= 0 && cfg->num_active_checks < c->m) ||
                         (cfg->rule != 0 && cfg->num_refresh_vars >= 0 && cfg->num_refresh_vars < c->n);
@@ -317,7 +327,7 @@ static int decode_impl(ldpc_code *c, const ldpc_decode_config *cfg, const void *
     if (cfg->rule == LDPC_RULE_LNMS && (quirks || (cfg->num_active_checks >= 0 && cfg->num_active_checks < c->m) || cfg->clip_post > 0.0))
         return fail(LDPC_ERR_UNSUPPORTED, "layered min-sum has no num_active_checks / num_refresh_vars / clip_post");
     // the compiled-in R1 kernels carry no posterior clip (the reference's R1 has none, bpsk.py:235-237)
-    const bool spec_ok = !(cfg->rule == LDPC_RULE_R1 && cfg->clip_post > 0.0);
+    const bool spec_ok = !((cfg->rule == LDPC_RULE_R1 || cfg->rule == LDPC_RULE_OMS) && cfg->clip_post > 0.0);
     if (kernel == LDPC_KERNEL_AUTO && c->has_qc && !quirks && c->spec_id >= 0 && spec_ok) {
         bool supported = false;
         hipError_t e = launch_spec(c->spec_id, *cfg, compute_dtype, io, c->num_cus, &g_kernel, &supported);
@@ -344,6 +354,7 @@ static int decode_impl(ldpc_code *c, const ldpc_decode_config *cfg, const void *
             case 2: e = launch_qc_rule_2(c->qc, *cfg, compute_dtype, io, c->num_cus, &g_kernel, &supported); break;
             case 3: e = launch_qc_rule_3(c->qc, *cfg, compute_dtype, io, c->num_cus, &g_kernel, &supported); break;
             case 4: e = launch_qc_rule_4(c->qc, *cfg, compute_dtype, io, c->num_cus, &g_kernel, &supported); break;
+            case 6: e = launch_qc_rule_6(c->qc, *cfg, compute_dtype, io, c->num_cus, &g_kernel, &supported); break;
         }
         if (e != hipSuccess) return fail(LDPC_ERR_HIP, "circulant kernel launch: %s", hipGetErrorString(e));
         if (supported) return LDPC_OK;
@@ -432,10 +443,9 @@ extern "C" int32_t ldpc_count_errors(const uint8_t *hard_dev, const uint8_t *ref
     return LDPC_OK;
 }
 
-extern "C" int32_t ldpc_channel_llr(const uint8_t *ref_dev, int64_t ref_stride, int64_t frames, int32_t n,
-                                    double sigma2, double gain, int32_t plus_is_bit, int32_t prefix_len,
-                                    double prefix_llr, uint64_t seed, uint64_t first_frame, void *llr_dev,
-                                    int32_t llr_dtype, void *stream)
+static int channel_impl(const uint8_t *ref_dev, int64_t ref_stride, int64_t frames, int32_t n, double sigma2,
+                        double gain, int32_t plus_is_bit, int32_t prefix_len, double prefix_llr, uint64_t seed,
+                        uint64_t first_frame, double cfo, double phase0, void *llr_dev, int32_t llr_dtype, void *stream)
 {
     if (frames < 0 || n <= 0) return fail(LDPC_ERR_ARG, "bad frame count or n");
     if (frames == 0) return LDPC_OK;
@@ -443,9 +453,45 @@ extern "C" int32_t ldpc_channel_llr(const uint8_t *ref_dev, int64_t ref_stride, 
     if (llr_dtype != LDPC_F32 && llr_dtype != LDPC_F64) return fail(LDPC_ERR_ARG, "dtype must be LDPC_F32 or LDPC_F64");
     if (ref_dev && ref_stride != 0 && ref_stride != n) return fail(LDPC_ERR_ARG, "ref_stride must be 0 or n");
     if (!(sigma2 >= 0.0) || prefix_len < 0) return fail(LDPC_ERR_ARG, "negative noise variance or prefix length");
+    if (!(cfo > -0.5 && cfo < 0.5) || !(phase0 > -128.0 && phase0 < 128.0))
+        return fail(LDPC_ERR_ARG, "frequency offset must lie within half a cycle per symbol, phase within 128 cycles");
     hipError_t e = launch_channel_llr(ref_dev, ref_stride, frames, n, sigma2, gain, plus_is_bit != 0, prefix_len,
-                                      prefix_llr, seed, first_frame, llr_dev, llr_dtype,
+                                      prefix_llr, seed, first_frame, cfo, phase0, llr_dev, llr_dtype,
                                       reinterpret_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(LDPC_ERR_HIP, "channel_llr launch: %s", hipGetErrorString(e));
+    return LDPC_OK;
+}
+
+extern "C" int32_t ldpc_channel_llr(const uint8_t *ref_dev, int64_t ref_stride, int64_t frames, int32_t n,
+                                    double sigma2, double gain, int32_t plus_is_bit, int32_t prefix_len,
+                                    double prefix_llr, uint64_t seed, uint64_t first_frame, void *llr_dev,
+                                    int32_t llr_dtype, void *stream)
+{
+    return channel_impl(ref_dev, ref_stride, frames, n, sigma2, gain, plus_is_bit, prefix_len, prefix_llr, seed,
+                        first_frame, 0.0, 0.0, llr_dev, llr_dtype, stream);
+}
+
+extern "C" int32_t ldpc_channel_llr_doppler(const uint8_t *ref_dev, int64_t ref_stride, int64_t frames, int32_t n,
+                                            double sigma2, double gain, int32_t plus_is_bit, int32_t prefix_len,
+                                            double prefix_llr, uint64_t seed, uint64_t first_frame,
+                                            double cfo_cycles_per_symbol, double phase0_cycles, void *llr_dev,
+                                            int32_t llr_dtype, void *stream)
+{
+    return channel_impl(ref_dev, ref_stride, frames, n, sigma2, gain, plus_is_bit, prefix_len, prefix_llr, seed,
+                        first_frame, cfo_cycles_per_symbol, phase0_cycles, llr_dev, llr_dtype, stream);
+}
+
+extern "C" int32_t ldpc_decode_segments(const ldpc_segment *segs, int32_t n_segs, const ldpc_decode_config *cfg,
+                                        int32_t llr_dtype, int32_t compute_dtype, int32_t kernel)
+{
+    if (n_segs < 0 || (n_segs > 0 && !segs)) return fail(LDPC_ERR_ARG, "bad segment list");
+    for (int i = 0; i < n_segs; ++i) {
+        const ldpc_segment &s = segs[i];
+        if (int rc = decode_impl(s.code, cfg, s.llr_dev, llr_dtype, compute_dtype, kernel, s.frames, s.hard_dev,
+                                 s.iters_dev, s.converged_dev, s.posterior_dev, s.stream, false)) {
+            g_err = "segment " + std::to_string(i) + ": " + g_err;
+            return rc;
+        }
+    }
     return LDPC_OK;
 }

@@ -149,7 +149,7 @@ class _EncoderBase:
     def _config(self, base: config.DecodeConfig) -> config.DecodeConfig:
         if not self.compat_loop_bounds:
             return base
-        if base.rule == config.RULE_R0:
+        if base.rule in (config.RULE_R0, config.RULE_BF):
             return base.with_(num_active_checks=min(int(self.m), self.H.shape[0]))
         if self.n > self.H.shape[1]:
             raise IndexError("self.n exceeds the matrix width: the reference indexes H out of bounds here")
@@ -190,6 +190,14 @@ class LdpcPyEncoder(_EncoderBase):
         if os.path.exists("parityMatrix.txt"):
             return codes.read_parity_matrix("parityMatrix.txt")
         return codes.load_packaged("wifi648").dense()
+
+    def bitFlipDecode(self, codeword):
+        """ldpc.py:82-135: hard-decision bit flipping.  Returns the bit error rate over all n bits
+        whether or not a codeword was reached, and sets no attribute, as the reference does."""
+        cfg = self._config(config.BF)
+        y = np.asarray(codeword, dtype=np.float64)[None, :]
+        res = self.decoder.decode(y, cfg)
+        return float(np.sum(np.asarray(self.originalEncoded) != res.hard[0]) / self.H.shape[1])
 
     def minSumDecode(self, codeword, M=2):
         if M != 2:

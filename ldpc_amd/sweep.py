@@ -77,9 +77,11 @@ def _empty_outputs(cw, llr, device):
 
 
 def noisy_batch(code: CompiledCode, cw, snr_db: float, cfg: DecodeConfig, seed, device, llr_dtype=None,
-                llr_scale_snr_db: Optional[float] = None, first_frame: int = 0) -> DeviceBatch:
+                llr_scale_snr_db: Optional[float] = None, first_frame: int = 0, cfo: float = 0.0,
+                phase0: float = 0.0) -> DeviceBatch:
     """Channel LLRs for the codewords ``cw`` from the library's own kernel (ldpc_channel_llr): frame
-    f gets the noise of absolute frame ``first_frame + f``, whatever batch or rank generates it."""
+    f gets the noise of absolute frame ``first_frame + f``, whatever batch or rank generates it.
+    ``cfo`` / ``phase0``: the Doppler-shifted channel (ldpc_channel_llr_doppler)."""
     import torch
 
     from . import channel
@@ -91,7 +93,7 @@ def noisy_batch(code: CompiledCode, cw, snr_db: float, cfg: DecodeConfig, seed, 
         channel.channel_llr_device(cw.data_ptr(), n, frames, n, snr_db, cfg, key, first_frame, llr.data_ptr(),
                                    np.float32 if llr_dtype == torch.float32 else np.float64,
                                    stream=torch.cuda.current_stream().cuda_stream,
-                                   llr_scale_snr_db=llr_scale_snr_db)
+                                   llr_scale_snr_db=llr_scale_snr_db, cfo=cfo, phase0=phase0)
     return _empty_outputs(cw, llr, device)
 
 
@@ -136,6 +138,48 @@ def decode_batch(dec: Decoder, batch: DeviceBatch, cfg: DecodeConfig, compute_dt
     return dec.decode_device(batch.llr.data_ptr(), np_dtype, batch.llr.shape[0], batch.hard.data_ptr(),
                              batch.iters.data_ptr(), batch.converged.data_ptr(), cfg,
                              compute_dtype=compute_dtype, stream=stream, kernel=kernel)
+
+
+_side_streams = {}
+
+
+def decode_mixed(parts, cfg: DecodeConfig, compute_dtype=np.float64, kernel: int = 0, counters=None):
+    """Decode one batch that mixes frames of several codes: ``parts`` is a list of
+    (Decoder, DeviceBatch), one per code; a single ``ldpc_decode_segments`` call enqueues every part
+    on a stream of its own, so the codes are decoded side by side.  With ``counters`` (an int64[5]
+    device tensor) the error statistics of all parts are added into it.  Returns the kernel names."""
+    import ctypes
+
+    import torch
+
+    from . import _lib
+    from .config import CDecodeConfig
+
+    lib = _lib.load()
+    cur = torch.cuda.current_stream()
+    dev = parts[0][1].llr.device
+    streams = _side_streams.setdefault(dev, [])
+    while len(streams) < len(parts):
+        streams.append(torch.cuda.Stream(device=dev))
+    segs = (_lib.CSegment * len(parts))()
+    llr_dtype = parts[0][1].llr.dtype
+    for i, (dec, bt) in enumerate(parts):
+        if bt.llr.dtype != llr_dtype:
+            raise TypeError("all parts of a mixed batch share one LLR type")
+        streams[i].wait_stream(cur)          # the LLRs were produced on the current stream
+        segs[i] = _lib.CSegment(dec._h.value, bt.llr.data_ptr(), bt.llr.shape[0], bt.hard.data_ptr(), bt.iters.data_ptr(),
+                                bt.converged.data_ptr(), None, streams[i].cuda_stream)
+    ccfg = CDecodeConfig.from_config(cfg)
+    _lib.check(lib.ldpc_decode_segments(segs, len(parts), ctypes.byref(ccfg), 0 if llr_dtype == torch.float32 else 1,
+                                        1 if np.dtype(compute_dtype) == np.float64 else 0, kernel))
+    names = []
+    for i, (dec, bt) in enumerate(parts):
+        if counters is not None:
+            dec.count_errors_device(bt.hard.data_ptr(), bt.ref.data_ptr(), dec.code.n, bt.iters.data_ptr(),
+                                    bt.converged.data_ptr(), bt.llr.shape[0], counters.data_ptr(),
+                                    stream=streams[i].cuda_stream)
+        cur.wait_stream(streams[i])
+    return _lib.last_kernel()
 
 
 def count_errors(dec: Decoder, batch: DeviceBatch, stream: Optional[int] = None) -> None:

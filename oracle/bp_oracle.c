@@ -16,6 +16,7 @@
  *   R4  /root/reference/channel.py:260-398  phi-function sum-product
  *   syndrome: /root/reference/ldpc.py:76-80
  *   LNMS row-layered normalised min-sum: a build extension with no counterpart in the reference
+ *   OMS  (rule 6) offset min-sum, flooding, R1's conventions: likewise a build extension
  *
  * Build: make -C oracle   (gcc -O2 -fopenmp -shared)
  */
@@ -38,6 +39,7 @@ typedef struct {
     double clip_tanh_arg;      /* R2: 20 (bpsk.py:333); <=0 = none */
     double clip_prod;          /* R2: 0.999999999 (bpsk.py:337); R3: 0.99999999 (channel.py:473) */
     double clip_post;          /* R2: 30, R3: 50, R4: 500 */
+    double offset;             /* rule 6 (offset min-sum, build extension): beta */
 } oracle_cfg;
 
 typedef struct {
@@ -162,9 +164,9 @@ static void decode_ext(const oracle_code *c, const oracle_cfg *g, const double *
         /* check nodes */
         for (int j = 0; j < m; j++) {
             int e0 = c->row_ptr[j], e1 = c->row_ptr[j + 1];
-            if (rule == 1 && e1 - e0 < 2) continue;
+            if ((rule == 1 || rule == 6) && e1 - e0 < 2) continue;
             for (int e = e0; e < e1; e++) {
-                if (rule == 1) {
+                if (rule == 1 || rule == 6) {
                     double mn = INFINITY, sg = 1.0;
                     for (int f = e0; f < e1; f++) {
                         if (f == e) continue;
@@ -174,7 +176,13 @@ static void decode_ext(const oracle_code *c, const oracle_cfg *g, const double *
                         if (s == 0.0) s = 1.0;
                         sg *= s;
                     }
-                    r[e] = g->scale * mn * sg;
+                    if (rule == 6) { /* offset min-sum: max(scale * min - offset, 0) * sign */
+                        double mag = g->scale * mn - g->offset;
+                        if (!(mag > 0)) mag = 0.0;
+                        r[e] = mag * sg;
+                    } else {
+                        r[e] = g->scale * mn * sg;
+                    }
                 } else if (rule == 2 || rule == 3) {
                     double prod = 1.0;
                     for (int f = e0; f < e1; f++) {
@@ -231,7 +239,7 @@ int bp_oracle_decode(const oracle_code *code, const oracle_cfg *cfg, const doubl
                      int64_t frames, uint8_t *hard, int32_t *iters, uint8_t *converged,
                      double *posterior, int nthreads)
 {
-    if (!code || !cfg || cfg->rule < 0 || cfg->rule > 4 || cfg->max_iters < 1) return -1; /* layered: bp_oracle_decode_lnms */
+    if (!code || !cfg || cfg->rule < 0 || cfg->rule == 5 || cfg->rule > 6 || cfg->max_iters < 1) return -1; /* layered: bp_oracle_decode_lnms */
     for (int j = 0; j < code->m; j++)
         if (code->row_ptr[j + 1] - code->row_ptr[j] > 64) return -1;
 #ifdef _OPENMP
@@ -334,6 +342,52 @@ int bp_oracle_decode_lnms(const oracle_code *code, const oracle_cfg *cfg, const 
             }
         }
         free(P); free(R);
+    }
+    return 0;
+}
+
+/* ---------------------------------------------------------------- bit flipping, ldpc.py:82-135
+ * bits = 0 if sample > 0 else 1 (ldpc.py:86-90); at most max_iters passes, each preceded by the
+ * syndrome test on every row (ldpc.py:103); in a pass the first num_active_checks rows (int(self.m),
+ * ldpc.py:113) vote +1 / -1 on each of their bits according to the parity of the check's other bits
+ * (ldpc.py:123-128) and a bit flips when its total exceeds len(Ej) / 2 of the last row visited
+ * (ldpc.py:130-132).  iters = passes made, converged = a syndrome test passed.
+ */
+int bp_oracle_bitflip(const oracle_code *code, const oracle_cfg *cfg, const double *samples, int64_t frames,
+                      uint8_t *hard, int32_t *iters, uint8_t *converged, int nthreads)
+{
+    if (!code || !cfg || cfg->max_iters < 1) return -1;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+    const int n = code->n, m = code->m;
+    const int mact = cfg->num_active_checks < 0 || cfg->num_active_checks > m ? m : cfg->num_active_checks;
+#pragma omp parallel
+    {
+        int *votes = malloc(sizeof(int) * (size_t)n);
+        uint8_t *msg = malloc((size_t)n);
+#pragma omp for schedule(dynamic, 4)
+        for (int64_t f = 0; f < frames; f++) {
+            uint8_t *b = hard + f * n;
+            for (int i = 0; i < n; i++) b[i] = samples[f * n + i] > 0 ? 0 : 1;
+            int t = 0, ok = 0, last_deg = 0;
+            for (; t < cfg->max_iters; t++) {
+                if (syndrome_ok(code, b)) { ok = 1; break; }
+                memcpy(msg, b, (size_t)n);
+                memset(votes, 0, sizeof(int) * (size_t)n);
+                for (int j = 0; j < mact; j++) {
+                    int e0 = code->row_ptr[j], e1 = code->row_ptr[j + 1], par = 0;
+                    for (int e = e0; e < e1; e++) par ^= msg[code->col_idx[e]];
+                    for (int e = e0; e < e1; e++) votes[code->col_idx[e]] += (par ^ msg[code->col_idx[e]]) ? 1 : -1;
+                    last_deg = e1 - e0;
+                }
+                for (int i = 0; i < n; i++)
+                    if (votes[i] > last_deg / 2.0) b[i] ^= 1;
+            }
+            iters[f] = t;
+            converged[f] = (uint8_t)ok;
+        }
+        free(votes); free(msg);
     }
     return 0;
 }

@@ -12,7 +12,9 @@ Two independent restatements of the reference's decoders live here; only tests/,
   differences for the sum-product rules (libm instead of numpy transcendentals).
 
 Rules follow /root/reference/ldpc.py:137-227 (R0), bpsk.py:154-260 (R1), bpsk.py:263-387 (R2),
-channel.py:402-513 (R3), channel.py:260-398 (R4); syndrome ldpc.py:76-80.
+channel.py:402-513 (R3), channel.py:260-398 (R4); syndrome ldpc.py:76-80.  Rule 5 (row-layered
+min-sum) and rule 6 (offset min-sum, flooding, R1's conventions) are build extensions with no
+counterpart in the reference: for them these oracles are the definition, not a restatement.
 """
 from __future__ import annotations
 
@@ -167,22 +169,25 @@ def numpy_decode(code, cfg, llr: np.ndarray, want_trace: bool = False):
                 if d < 2:
                     r[:, base] = 0.0
                     continue
-            if rule == 1 and d < 2:
+            if rule in (1, 6) and d < 2:
                 continue
             vals = [src[:, base + p] for p in range(d)]       # each [Bact, nchecks]
             for tp in range(d):
                 others = [vals[p] for p in range(d) if p != tp]
-                if rule in (0, 1):
+                if rule in (0, 1, 6):
                     mn = None
                     sg = None
                     for v in others:
                         a = np.abs(v)
                         mn = a if mn is None else np.minimum(mn, a)
                         s = np.sign(v)
-                        if rule == 1:
+                        if rule != 0:
                             s = np.where(s == 0.0, 1.0, s)
                         sg = s if sg is None else sg * s
-                    out = mn * sg if rule == 0 else cfg.scale * mn * sg
+                    if rule == 6:   # offset min-sum (build extension): max(scale * min - offset, 0) * sign
+                        out = np.maximum(cfg.scale * mn - cfg.offset, 0.0) * sg
+                    else:
+                        out = mn * sg if rule == 0 else cfg.scale * mn * sg
                     if rule == 0:
                         out = np.where(live[None, :], out, 0.0)
                 elif rule in (2, 3):
@@ -266,7 +271,7 @@ class _OracleCfg(ctypes.Structure):
                 ("early_exit", ctypes.c_int32), ("float_syndrome0", ctypes.c_int32),
                 ("num_active_checks", ctypes.c_int32), ("num_refresh_vars", ctypes.c_int32),
                 ("scale", ctypes.c_double), ("clip_tanh_arg", ctypes.c_double),
-                ("clip_prod", ctypes.c_double), ("clip_post", ctypes.c_double)]
+                ("clip_prod", ctypes.c_double), ("clip_post", ctypes.c_double), ("offset", ctypes.c_double)]
 
 
 class _OracleCode(ctypes.Structure):
@@ -382,6 +387,58 @@ def c_decode_lnms(code, cfg, llr, nthreads: int = 0, use_float: bool = False, wa
     return hard, iters, conv.astype(bool), post
 
 
+def numpy_bitflip(code, cfg, samples):
+    """Bit flipping as ldpc.py:82-135 does it, one frame at a time with the reference's own loops
+    over numpy arrays.  Returns (hard u8[B,n], iters i32[B], converged bool[B])."""
+    y = np.array(samples, dtype=np.float64, ndmin=2)
+    B, n = y.shape
+    m = code.m
+    mact = m if cfg.num_active_checks < 0 or cfg.num_active_checks > m else int(cfg.num_active_checks)
+    hard = np.zeros((B, n), np.uint8)
+    iters = np.zeros(B, np.int32)
+    conv = np.zeros(B, bool)
+    rows = [code.col_idx[code.row_ptr[j]:code.row_ptr[j + 1]] for j in range(m)]
+    for f in range(B):
+        bits = np.where(y[f] > 0, 0, 1).astype(np.int64)             # ldpc.py:86-90
+        t = 0
+        while t < cfg.max_iters:                                     # ldpc.py:102
+            if not code.syndrome(bits).any():                        # ldpc.py:103
+                conv[f] = True
+                break
+            msgs = bits.copy()
+            votes = np.zeros(n, np.int64)
+            Ej = np.zeros(0, np.int64)
+            for j in range(mact):                                    # ldpc.py:113
+                Ej = rows[j]
+                par = int(np.bitwise_xor.reduce(msgs[Ej])) if len(Ej) else 0
+                votes[Ej] += np.where((par ^ msgs[Ej]) == 1, 1, -1)  # ldpc.py:123-128
+            bits = np.where(votes > len(Ej) / 2, bits ^ 1, bits)      # ldpc.py:130-132
+            t += 1
+        hard[f] = bits
+        iters[f] = t
+    return hard, iters, conv
+
+
+def c_bitflip(code, cfg, samples, nthreads: int = 0):
+    lib = _load_c()
+    y = np.ascontiguousarray(np.array(samples, dtype=np.float64, ndmin=2))
+    B, n = y.shape
+    arrs = [np.ascontiguousarray(a, dtype=np.int32) for a in (code.row_ptr, code.col_idx, code.col_ptr, code.csc_edge)]
+    ccode = _OracleCode(code.m, code.n, code.num_edges, *[a.ctypes.data for a in arrs])
+    ccfg = _OracleCfg(7, int(cfg.max_iters), 1, 0, int(cfg.num_active_checks), -1, 1.0, 0.0, 0.0, 0.0, 0.0)
+    hard = np.zeros((B, n), np.uint8)
+    iters = np.zeros(B, np.int32)
+    conv = np.zeros(B, np.uint8)
+    lib.bp_oracle_bitflip.restype = ctypes.c_int
+    lib.bp_oracle_bitflip.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    rc = lib.bp_oracle_bitflip(ctypes.byref(ccode), ctypes.byref(ccfg), y.ctypes.data, B, hard.ctypes.data,
+                               iters.ctypes.data, conv.ctypes.data, int(nthreads))
+    if rc != 0:
+        raise ValueError("bp_oracle_bitflip rejected its arguments")
+    return hard, iters, conv.astype(bool)
+
+
 def c_max_threads() -> int:
     return int(_load_c().bp_oracle_max_threads())
 
@@ -398,7 +455,7 @@ def c_decode(code, cfg, llr: np.ndarray, nthreads: int = 0, want_posterior: bool
     ccfg = _OracleCfg(int(cfg.rule), int(cfg.max_iters), int(bool(cfg.early_exit)),
                       int(bool(cfg.float_syndrome0)), int(cfg.num_active_checks),
                       int(cfg.num_refresh_vars), float(cfg.scale), float(cfg.clip_tanh_arg),
-                      float(cfg.clip_prod), float(cfg.clip_post))
+                      float(cfg.clip_prod), float(cfg.clip_post), float(getattr(cfg, "offset", 0.0)))
     hard = np.zeros((B, n), np.uint8)
     iters = np.zeros(B, np.int32)
     conv = np.zeros(B, np.uint8)

@@ -47,11 +47,20 @@ def standard_normals(frames, n, seed, first_frame=0):
     return np.stack([n0, n1, n2, n3], axis=-1).reshape(frames, quads * 4)[:, :n]
 
 
-def channel_llr(ref, frames, n, sigma2, gain, plus_is_bit, prefix_len, prefix_llr, seed, first_frame=0):
+def channel_llr(ref, frames, n, sigma2, gain, plus_is_bit, prefix_len, prefix_llr, seed, first_frame=0,
+                cfo=0.0, phase0=0.0):
+    """``cfo`` / ``phase0`` (cycles per symbol, cycles): the Doppler-shifted channel of
+    ``ldpc_channel_llr_doppler`` — symbol i is scaled by sinc(cfo) * cos(2 pi (cfo (i + 1/2) + phase0));
+    build-defined from the scale factor of /root/reference/plotDoppler.py:14-16, nothing pins it."""
     f32 = np.float32
     z = standard_normals(frames, n, seed, first_frame)
     b = np.zeros((frames, n), f32) if ref is None else np.broadcast_to(np.asarray(ref), (frames, n)).astype(f32)
     x = f32(2) * b - f32(1) if plus_is_bit else f32(1) - f32(2) * b
+    if cfo or phase0:
+        amp = f32(np.sinc(cfo))                                  # sin(pi cfo) / (pi cfo)
+        turns = f32(cfo) * (np.arange(n, dtype=f32) + f32(0.5)) + f32(phase0)
+        turns = turns - np.floor(turns)
+        x = x * (amp * np.cos(f32(6.283185307179586) * turns))[None, :]
     llr = f32(gain) * (x + f32(np.sqrt(sigma2)) * z)
     llr[:, :prefix_len] = f32(prefix_llr)
     return llr

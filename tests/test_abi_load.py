@@ -25,12 +25,13 @@ def test_library_exports_every_declared_symbol():
     for name in names:
         assert hasattr(lib, name), name
     assert sorted(_lib.SYMBOLS) == names
-    assert lib.ldpc_abi_version() == 1
+    assert lib.ldpc_abi_version() == 2
 
 
 def test_config_struct_layout_matches_header():
-    # 6 x int32 then 4 x double, no padding surprises
-    assert ctypes.sizeof(config.CDecodeConfig) == 6 * 4 + 4 * 8
+    # 6 x int32 then 5 x double, no padding surprises
+    assert ctypes.sizeof(config.CDecodeConfig) == 6 * 4 + 5 * 8
+    assert config.CDecodeConfig.from_config(config.OMS).offset == 0.5
     c = config.CDecodeConfig.from_config(config.R3)
     assert (c.rule, c.max_iters, c.scale, c.clip_prod, c.clip_post) == (3, 50, 0.85, 0.99999999, 50.0)
 
