@@ -78,10 +78,12 @@ def _empty_outputs(cw, llr, device):
 
 def noisy_batch(code: CompiledCode, cw, snr_db: float, cfg: DecodeConfig, seed, device, llr_dtype=None,
                 llr_scale_snr_db: Optional[float] = None, first_frame: int = 0, cfo: float = 0.0,
-                phase0: float = 0.0) -> DeviceBatch:
+                phase0: float = 0.0, compat_prefix: bool = False) -> DeviceBatch:
     """Channel LLRs for the codewords ``cw`` from the library's own kernel (ldpc_channel_llr): frame
     f gets the noise of absolute frame ``first_frame + f``, whatever batch or rank generates it.
-    ``cfo`` / ``phase0``: the Doppler-shifted channel (ldpc_channel_llr_doppler)."""
+    ``cfo`` / ``phase0``: the Doppler-shifted channel (ldpc_channel_llr_doppler).  ``compat_prefix``:
+    the first 80 LLRs are overwritten as the reference's R1 / R3 / R4 methods do (bpsk.py:163,
+    channel.py:412)."""
     import torch
 
     from . import channel
@@ -93,7 +95,8 @@ def noisy_batch(code: CompiledCode, cw, snr_db: float, cfg: DecodeConfig, seed, 
         channel.channel_llr_device(cw.data_ptr(), n, frames, n, snr_db, cfg, key, first_frame, llr.data_ptr(),
                                    np.float32 if llr_dtype == torch.float32 else np.float64,
                                    stream=torch.cuda.current_stream().cuda_stream,
-                                   llr_scale_snr_db=llr_scale_snr_db, cfo=cfo, phase0=phase0)
+                                   llr_scale_snr_db=llr_scale_snr_db, cfo=cfo, phase0=phase0,
+                                   compat_prefix=compat_prefix)
     return _empty_outputs(cw, llr, device)
 
 
@@ -242,7 +245,8 @@ SWEEP_CHUNK = 1 << 14
 
 def ber_sweep(code: CompiledCode, G: Optional[np.ndarray], cfg: DecodeConfig, snrs_db, frames_per_point: int,
               device, compute_dtype=np.float64, seed=0, dec: Optional[Decoder] = None, batch: int = 1 << 18,
-              rank: Optional[int] = None, world: Optional[int] = None, reduce: bool = True):
+              rank: Optional[int] = None, world: Optional[int] = None, reduce: bool = True,
+              compat_prefix: bool = False):
     """Monte-Carlo error-rate sweep, the batched form of the reference's ``plotFrameError``
     (ldpc.py:637-667).  The ``frames_per_point`` frames of an SNR point are numbered 0, 1, ...; rank r
     of ``world`` decodes the contiguous range ``shard_range(frames_per_point, r, world)`` of them,
@@ -262,7 +266,8 @@ def ber_sweep(code: CompiledCode, G: Optional[np.ndarray], cfg: DecodeConfig, sn
         while pos < b:
             # one launch: the part of [pos, b) that lies in the next `per_launch`-aligned window
             end = min(b, (pos // per_launch + 1) * per_launch)
-            bt = make_batch_range(code, G, pos, end, frames_per_point, float(snr), cfg, seed=[seed, si], device=device)
+            bt = make_batch_range(code, G, pos, end, frames_per_point, float(snr), cfg, seed=[seed, si], device=device,
+                                  compat_prefix=compat_prefix)
             decode_batch(dec, bt, cfg, compute_dtype=compute_dtype)
             count_errors(dec, bt)
             total += bt.counters
@@ -277,7 +282,7 @@ def ber_sweep(code: CompiledCode, G: Optional[np.ndarray], cfg: DecodeConfig, sn
 
 
 def make_batch_range(code: CompiledCode, G, first: int, last: int, total: int, snr_db: float, cfg: DecodeConfig,
-                     seed, device, llr_dtype=None) -> DeviceBatch:
+                     seed, device, llr_dtype=None, compat_prefix: bool = False) -> DeviceBatch:
     """The frames [first, last) of a sweep point of ``total`` frames.  Codewords are drawn per
     ``SWEEP_CHUNK``-aligned chunk of absolute frame numbers (seed + [chunk]), noise comes from the
     library's channel kernel keyed by the absolute frame number: the result does not depend on how
@@ -292,4 +297,5 @@ def make_batch_range(code: CompiledCode, G, first: int, last: int, total: int, s
         cw = make_codewords(code, G, c1 - c0, seed + [c], device)
         parts.append(cw[max(first, c0) - c0:min(last, c1) - c0])
     cw = parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
-    return noisy_batch(code, cw, snr_db, cfg, seed, device, llr_dtype=llr_dtype, first_frame=first)
+    return noisy_batch(code, cw, snr_db, cfg, seed, device, llr_dtype=llr_dtype, first_frame=first,
+                       compat_prefix=compat_prefix)

@@ -42,3 +42,65 @@ def test_r0_ccsds_fer_inside_reference_interval():
         assert abs(p32["not_converged"] - p64["not_converged"]) <= 3 + 0.01 * p64["not_converged"]
         assert p64["converged_wrong"] == 0
     assert r64[0]["fer"] > r64[1]["fer"] > r64[2]["fer"] >= r64[3]["fer"]
+
+
+def _reference_counts():
+    import json
+    import os
+    from conftest import GOLDEN_DIR
+    with open(os.path.join(GOLDEN_DIR, "reference_counts.json")) as f:
+        return json.load(f)["counts"]
+
+
+@pytest.mark.parametrize("key", ["R1/wifi648", "R3/ccsds512"])
+def test_frame_error_rate_inside_interval_of_reference_counts(key):
+    """The reference's own decoders (bpsk.py:154-260 on 802.11n, channel.py:402-513 on CCSDS), run on
+    a few hundred random codewords per point by oracle/gen_reference_counts.py, against 2^17 frames
+    per point here: frame error rate inside the 99.9 % Clopper-Pearson interval of the reference's
+    counts, mean iteration count within 0.6."""
+    import torch
+    from ldpc_amd import sweep
+    rule, name = key.split("/")
+    counts = _reference_counts()[key]
+    code = codes.load_packaged(name)
+    G = codes.load_packaged_generator(name)
+    dev = torch.device("cuda", 0)
+    snrs = sorted(float(s) for s in counts)
+    cfg = config.PRESETS[rule]
+    res = sweep.ber_sweep(code, G, cfg, snrs, 1 << 17, dev, np.float64, seed=23, compat_prefix=True)
+    informative = 0
+    for p in res:
+        n_ref, k_ref, wrong_ref, _, it_ref = counts[str(p["es_n0_db"])]
+        lo, hi = clopper_pearson(k_ref, n_ref)
+        assert lo <= p["fer"] <= hi, (key, p["es_n0_db"], p["fer"], lo, hi)
+        assert abs(p["iterations"] / p["frames"] - it_ref / n_ref) < 0.6, (key, p["es_n0_db"])
+        informative += 0 < k_ref < n_ref
+    assert informative >= 2, "the reference counts must straddle the waterfall"
+
+
+@pytest.mark.parametrize("name,snrs", [("wifi648", [-1.5, -1.0, -0.5, 0.0]), ("nr_bg2_z40", [-6.5, -6.0, -5.5, -5.0])])
+def test_layered_rule_anchored_to_reference_pinned_flooding_rule(name, snrs):
+    """The layered rule has no counterpart in the reference; what ties it to one is its decoding
+    performance on the reference's own matrices against the reference-pinned flooding rule R1
+    (bpsk.py:154-260), same frames, float64, 2^17 frames per point: ten layered sweeps are never worse
+    than ten flooding iterations and lie between R1 at twenty iterations and 1.7 times that (measured
+    1.02-1.59 over these eight points; a layered sweep is worth almost two flooding iterations)."""
+    import torch
+    from ldpc_amd import sweep
+    from ldpc_amd.decoder import Decoder
+    code = codes.load_packaged(name)
+    G = codes.load_packaged_generator(name) if name == "wifi648" else None
+    dev = torch.device("cuda", 0)
+    dec = Decoder(code)
+    frames = 1 << 17
+    run = lambda cfg: sweep.ber_sweep(code, G, cfg, snrs, frames, dev, np.float64, seed=17, dec=dec)
+    r10, r20 = run(config.R1.with_(max_iters=10)), run(config.R1.with_(max_iters=20))
+    l10, l5 = run(config.LNMS.with_(max_iters=10)), run(config.LNMS.with_(max_iters=5))
+    for a10, a20, b10, b5 in zip(r10, r20, l10, l5):
+        k20 = a20["not_converged"]
+        lo20, hi20 = clopper_pearson(k20, frames)
+        assert b10["not_converged"] <= a10["not_converged"], (name, a10["es_n0_db"])
+        assert 0.9 * lo20 <= b10["fer"] <= 1.7 * hi20, (name, a10["es_n0_db"], b10["fer"], lo20, hi20)
+        assert b5["not_converged"] >= b10["not_converged"]
+        # bit error rates tell the same story
+        assert b10["ber"] <= a10["ber"] and b10["ber"] <= 1.7 * a20["ber"] + 1e-6

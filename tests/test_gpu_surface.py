@@ -140,7 +140,7 @@ def test_edge_cases_of_the_abi():
         dec.decode(np.zeros((1, code.n)), config.R1.with_(max_iters=0))
     assert ei.value.code == _lib.LDPC_ERR_ARG
     with pytest.raises(_lib.LdpcError):
-        dec.decode(np.zeros((1, code.n)), config.DecodeConfig(rule=7))
+        dec.decode(np.zeros((1, code.n)), config.DecodeConfig(rule=8))
     one = dec.decode(np.full((1, code.n), 5.0), config.R1)       # single frame, all-zero word at once
     assert one.converged[0] and one.iters[0] == 0 and not one.hard.any()
     # a batch that is not a multiple of the frames-per-workgroup of any kernel

@@ -60,7 +60,7 @@ def test_mixed_ccsds_and_5g_batch(rule, c_oracle):
     dev = torch.device("cuda", 0)
     cfg = config.PRESETS[rule].with_(max_iters=25)
     cfo = channel.doppler_cfo(4000.0, compensated=0.999)
-    spec = [("ccsds512", 3000, 1.0), ("nr_bg2_z40_r1400", 700, -3.5)]
+    spec = [("ccsds512", 3000, 0.0), ("nr_bg2_z40_r1400", 700, -4.5)]
     parts, singles = [], []
     counters = torch.zeros((5,), dtype=torch.int64, device=dev)
     for name, frames, snr in spec:
