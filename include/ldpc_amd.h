@@ -236,6 +236,57 @@ int32_t ldpc_channel_llr_doppler(const uint8_t *ref_dev, int64_t ref_stride, int
                                  int32_t llr_dtype, void *stream);
 
 /*
+ * Encoder for circulant codes, on the device: replaces `numpy.dot(self.G, message) % 2`
+ * (/root/reference/ldpc.py:46) and the dense generator of pyldpc.coding_matrix (ldpc.py:369) for
+ * codes whose generator would be too large to hold (5G NR) or is itself block-circulant (CCSDS).
+ * The code is handed over as a schedule over block columns (Z-vectors of bits): information block
+ * k of the message (bits [k Z, (k+1) Z)) is block column info_cols[k] of the codeword; step s, in
+ * order, produces block column step_out[s] as the XOR over its terms t in
+ * [step_ptr[s], step_ptr[s+1]) of block column term_col[t] rotated by term_shift[t]:
+ *     out[z] ^= col[(z + shift) mod Z].
+ * Block columns [0, nb) form the codeword, [nb, n_cols) are temporaries.  step_level is
+ * non-decreasing; a step may only read information columns and outputs of steps of LOWER levels
+ * (checked).  ldpc_amd/encoder.py derives schedules from a parity-check matrix with 5G NR / 802.11n
+ * parity structure or from a block-circulant systematic generator.
+ * ldpc_encode_batch: msg_dev [frames, k_cols * Z] bytes (bit 0 of each), cw_dev [frames, nb * Z]
+ * bytes of 0 / 1; enqueued on `stream`.
+ */
+typedef struct ldpc_encoder ldpc_encoder;
+int32_t ldpc_encoder_create(int32_t Z, int32_t n_cols, int32_t nb, int32_t k_cols, const int32_t *info_cols,
+                            int32_t n_steps, const int32_t *step_out, const int32_t *step_ptr,
+                            const int32_t *step_level, const int32_t *term_col, const int32_t *term_shift,
+                            int32_t device, ldpc_encoder **out);
+void ldpc_encoder_destroy(ldpc_encoder *enc);
+int32_t ldpc_encode_batch(ldpc_encoder *enc, const uint8_t *msg_dev, int64_t frames, uint8_t *cw_dev, void *stream);
+
+/*
+ * Channel -> decode -> error accounting of `frames` frames in ONE launch: the body of the
+ * reference's Monte-Carlo loop (/root/reference/ldpc.py:644-667: encode + noise, ldpc.py:651 -> 52,
+ * decode, ldpc.py:654, count, ldpc.py:660-662) without LLRs or hard decisions ever reaching device
+ * memory.  The channel is that of ldpc_channel_llr / ldpc_channel_llr_doppler with the same noise
+ * stream (frame f gets the noise of absolute frame first_frame + f), the counters are those of
+ * ldpc_count_errors: the five numbers added to counters_dev equal, bit for bit, what the three
+ * calls in a row add for the same arguments.  ref_dev: transmitted codewords [frames, n]
+ * (ref_stride = n), one codeword for all frames (ref_stride = 0) or NULL (the all-zero codeword);
+ * 4-byte aligned.  Served for the compiled-in codes (rules R0, R1, OMS on the small ones, LNMS on
+ * all); LDPC_ERR_UNSUPPORTED otherwise, and the three calls are the fallback.
+ */
+typedef struct ldpc_channel_config {
+    double sigma2;                 /* noise variance, 1 / (2 * 10^(SNR/10)), ldpc.py:245 */
+    double gain;                   /* llr = gain * y: 2 / sigma2 (ldpc.py:144) or 1 / sigma2 (bpsk.py:273) */
+    double prefix_llr;             /* value of the overwritten prefix (bpsk.py:163, channel.py:412) */
+    double cfo_cycles_per_symbol;  /* Doppler channel, see ldpc_channel_llr_doppler; 0 = none */
+    double phase0_cycles;
+    uint64_t seed;
+    uint64_t first_frame;
+    int32_t plus_is_bit;           /* bit sent as +1: 1 (ldpc.py:257) or 0 (bpsk.py:240-243) */
+    int32_t prefix_len;
+} ldpc_channel_config;
+int32_t ldpc_sweep_batch(ldpc_code *code, const ldpc_decode_config *cfg, const ldpc_channel_config *channel,
+                         const uint8_t *ref_dev, int64_t ref_stride, int64_t frames, int32_t compute_dtype,
+                         uint64_t *counters_dev, void *stream);
+
+/*
  * One batch that mixes frames of several codes (e.g. CCSDS and 5G frames of one link), decoded by
  * one call: the batch is handed over as one segment per code, each with its own handle, buffers
  * and stream; every segment is enqueued on its stream, so segments on different streams run side

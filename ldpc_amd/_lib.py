@@ -20,7 +20,7 @@ KERNEL_AUTO, KERNEL_CSR, KERNEL_QC = 0, 1, 2
 #: every symbol include/ldpc_amd.h declares
 SYMBOLS = ["ldpc_last_error", "ldpc_abi_version", "ldpc_device_count", "ldpc_code_create_csr",
            "ldpc_code_attach_qc", "ldpc_code_destroy", "ldpc_code_info", "ldpc_decode_batch",
-           "ldpc_decode_batch_host", "ldpc_decode_batch_noalloc", "ldpc_noalloc_scratch_bytes", "ldpc_count_errors", "ldpc_channel_llr", "ldpc_channel_llr_doppler", "ldpc_decode_segments",
+           "ldpc_decode_batch_host", "ldpc_decode_batch_noalloc", "ldpc_noalloc_scratch_bytes", "ldpc_count_errors", "ldpc_channel_llr", "ldpc_channel_llr_doppler", "ldpc_decode_segments", "ldpc_sweep_batch", "ldpc_encoder_create", "ldpc_encoder_destroy", "ldpc_encode_batch",
            "ldpc_last_kernel"]
 
 
@@ -30,6 +30,15 @@ class CSegment(ctypes.Structure):
     _fields_ = [("code", ctypes.c_void_p), ("llr_dev", ctypes.c_void_p), ("frames", ctypes.c_int64),
                 ("hard_dev", ctypes.c_void_p), ("iters_dev", ctypes.c_void_p), ("converged_dev", ctypes.c_void_p),
                 ("posterior_dev", ctypes.c_void_p), ("stream", ctypes.c_void_p)]
+
+
+class CChannelConfig(ctypes.Structure):
+    """Binary image of ``ldpc_channel_config`` (include/ldpc_amd.h): the channel of a fused sweep."""
+
+    _fields_ = [("sigma2", ctypes.c_double), ("gain", ctypes.c_double), ("prefix_llr", ctypes.c_double),
+                ("cfo_cycles_per_symbol", ctypes.c_double), ("phase0_cycles", ctypes.c_double),
+                ("seed", ctypes.c_uint64), ("first_frame", ctypes.c_uint64), ("plus_is_bit", ctypes.c_int32),
+                ("prefix_len", ctypes.c_int32)]
 
 
 class LdpcError(RuntimeError):
@@ -106,6 +115,14 @@ def load() -> ctypes.CDLL:
     lib.ldpc_channel_llr_doppler.argtypes = [vp, i64, i64, i32, ctypes.c_double, ctypes.c_double, i32, i32,
                                              ctypes.c_double, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_double,
                                              ctypes.c_double, vp, i32, vp]
+    lib.ldpc_encoder_create.restype = i32
+    lib.ldpc_encoder_create.argtypes = [i32, i32, i32, i32, vp, i32, vp, vp, vp, vp, vp, i32, ctypes.POINTER(vp)]
+    lib.ldpc_encoder_destroy.restype = None
+    lib.ldpc_encoder_destroy.argtypes = [vp]
+    lib.ldpc_encode_batch.restype = i32
+    lib.ldpc_encode_batch.argtypes = [vp, vp, i64, vp, vp]
+    lib.ldpc_sweep_batch.restype = i32
+    lib.ldpc_sweep_batch.argtypes = [vp, ctypes.POINTER(CDecodeConfig), ctypes.POINTER(CChannelConfig), vp, i64, i64, i32, vp, vp]
     lib.ldpc_decode_segments.restype = i32
     lib.ldpc_decode_segments.argtypes = [ctypes.POINTER(CSegment), i32, ctypes.POINTER(CDecodeConfig), i32, i32, i32]
     _lib = lib

@@ -28,6 +28,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 UNITS = [(f"decode_spec_spaw_r{k}.o", "decode_spec_spaw.hip", [f"-DLDPC_SPAW_RULE={k}"]) for k in (2, 3, 4)]
 UNITS += [("decode_spec_spa.o", "decode_spec_spa.hip", []),
           ("decode_lnms.o", "decode_lnms.hip", []),
+          ("decode_lnms_fused.o", "decode_lnms.hip", ["-DLDPC_SPEC_FUSED"]),
+          ("decode_spec_fused.o", "decode_spec.hip", ["-DLDPC_SPEC_FUSED"]),
           ("decode_spec_r1w_r1.o", "decode_spec_r1w.hip", ["-DLDPC_R1W_RULE=1"]),
           ("decode_spec_r1w_r0.o", "decode_spec_r1w.hip", ["-DLDPC_R1W_RULE=0"]),
           ("decode_spec_r1w_r6.o", "decode_spec_r1w.hip", ["-DLDPC_R1W_RULE=6"]),
@@ -39,8 +41,9 @@ UNITS += [("decode_qc_r0.o", "decode_qc_r0.hip", []),
           ("ldpc_abi.o", "ldpc_abi.hip", []),
           ("count_errors.o", "count_errors.hip", []),
           ("channel.o", "channel.hip", []),
-          ("bitflip.o", "bitflip.hip", [])]
-HEADERS = ["bp_common.h", "extra_kernels.h", "bp_math.h", "spec_common.h", "spec_r1w_plan.h", os.path.join("gen", "codes_gen.h"),
+          ("bitflip.o", "bitflip.hip", []),
+          ("encode_qc.o", "encode_qc.hip", [])]
+HEADERS = ["bp_common.h", "extra_kernels.h", "sweep_fused.h", "bp_math.h", "spec_common.h", "spec_r1w_plan.h", os.path.join("gen", "codes_gen.h"),
            os.path.join(ROOT, "include", "ldpc_amd.h")]
 
 
@@ -59,6 +62,8 @@ def kernel_source_digest(kernel: str) -> str:
     import hashlib
 
     files = None
+    if kernel.startswith("fused_"):  # the same sources compiled with -DLDPC_SPEC_FUSED
+        kernel = kernel[len("fused_"):]
     for prefix in sorted(KERNEL_SOURCES, key=len, reverse=True):
         if kernel.startswith(prefix):
             files = KERNEL_SOURCES[prefix]
@@ -70,6 +75,21 @@ def kernel_source_digest(kernel: str) -> str:
         path = os.path.join(CSRC, f)
         h.update(open(path, "rb").read() if os.path.exists(path) else b"")
     return h.hexdigest()[:16]
+
+
+def _includes(path: str, seen=None):
+    """Files `path` includes with quotes, transitively (csrc/ and include/)."""
+    import re
+    seen = set() if seen is None else seen
+    for name in re.findall(r'^\s*#\s*include\s+"([^"]+)"', open(path).read(), flags=re.M):
+        for base in (os.path.dirname(path), CSRC, os.path.join(ROOT, "include")):
+            cand = os.path.normpath(os.path.join(base, name))
+            if os.path.exists(cand):
+                if cand not in seen:
+                    seen.add(cand)
+                    _includes(cand, seen)
+                break
+    return seen
 
 
 def _stale(target: str, deps) -> bool:
@@ -87,7 +107,7 @@ def build(force: bool = False, jobs: int = 8, verbose: bool = True) -> str:
     todo = []
     for obj, src, extra in UNITS:
         o, s = os.path.join(OBJ, obj), os.path.join(CSRC, src)
-        if force or _stale(o, [s] + headers):
+        if force or _stale(o, [s] + sorted(_includes(s))):
             todo.append((o, [HIPCC] + FLAGS + extra + ["-c", s, "-o", o]))
 
     def run(item):

@@ -73,6 +73,22 @@ def doppler_cfo(symbol_rate: float, relative_speed: float = RELATIVE_SPEED, wave
     return (doppler_scale(relative_speed, wave_speed) - 1.0) * carrier_hz * (1.0 - compensated) / symbol_rate
 
 
+def channel_parameters(snr_db: float, cfg: DecodeConfig, compat_prefix: bool = False, llr_scale_snr_db=None):
+    """(noise variance, LLR gain, prefix length, prefix value) of the device channel for ``cfg.rule``:
+    variance 1/(2*10^(SNR/10)) (ldpc.py:245), gain 2/sigma^2 (1/sigma^2 for R2, bpsk.py:273) taken at
+    ``llr_scale_snr_db`` if the receiver's SNR estimate differs from the channel's, and the rule's
+    overwritten prefix (bpsk.py:163, channel.py:412) when ``compat_prefix``."""
+    sigma2 = float(noise_variance(snr_db))
+    sigma2_llr = sigma2 if llr_scale_snr_db is None else float(noise_variance(llr_scale_snr_db))
+    gain = (1.0 if cfg.rule == RULE_R2 else 2.0) / sigma2_llr
+    plen, pval = 0, 0.0
+    if compat_prefix and cfg.rule == RULE_R1:
+        plen, pval = PUNCTURE_PREFIX, 1e-9
+    elif compat_prefix and cfg.rule in (RULE_R3, RULE_R4):
+        plen, pval = PUNCTURE_PREFIX, 0.0
+    return sigma2, gain, plen, pval
+
+
 def channel_llr_device(ref_ptr: int, ref_stride: int, frames: int, n: int, snr_db: float, cfg: DecodeConfig,
                        seed: int, first_frame: int, llr_ptr: int, llr_dtype=np.float32, stream: int = 0,
                        compat_prefix: bool = False, llr_scale_snr_db=None, cfo: float = 0.0,
@@ -85,14 +101,7 @@ def channel_llr_device(ref_ptr: int, ref_stride: int, frames: int, n: int, snr_d
     ``cfo`` (cycles per symbol, see ``doppler_cfo``) or ``phase0`` (cycles) selects the Doppler-shifted
     channel ``ldpc_channel_llr_doppler``."""
     from . import _lib
-    sigma2 = float(noise_variance(snr_db))
-    sigma2_llr = sigma2 if llr_scale_snr_db is None else float(noise_variance(llr_scale_snr_db))
-    gain = (1.0 if cfg.rule == RULE_R2 else 2.0) / sigma2_llr
-    plen, pval = 0, 0.0
-    if compat_prefix and cfg.rule == RULE_R1:
-        plen, pval = PUNCTURE_PREFIX, 1e-9
-    elif compat_prefix and cfg.rule in (RULE_R3, RULE_R4):
-        plen, pval = PUNCTURE_PREFIX, 0.0
+    sigma2, gain, plen, pval = channel_parameters(snr_db, cfg, compat_prefix, llr_scale_snr_db)
     dt = 1 if np.dtype(llr_dtype) == np.float64 else 0
     if cfo or phase0:
         _lib.check(_lib.load().ldpc_channel_llr_doppler(

@@ -21,59 +21,21 @@
 // = (absolute frame index, position / 4), two Box-Muller pairs per counter value.  A frame's noise
 // therefore depends only on (seed, frame index, position) - not on the batch it is generated in
 // or on the GPU that generates it, which is what lets ranks shard a sweep by frame ranges.
-#include "bp_common.h"
+#include "sweep_fused.h"
 
 namespace ldpc {
 
-struct Philox4 { unsigned x, y, z, w; };
-
-__device__ __forceinline__ Philox4 philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3,
-                                                 unsigned k0, unsigned k1)
-{
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-        const unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
-        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
-    }
-    return Philox4{c0, c1, c2, c3};
-}
-
-// two standard normals from two 32-bit words: u1 in (0, 1), radius up to 6.7 sigma
-__device__ __forceinline__ void box_muller(unsigned a, unsigned b, float &n0, float &n1)
-{
-    const float u1 = ((float)a + 0.5f) * 2.3283064365386963e-10f;  // 2^-32; never 0, may round to 1
-    const float u2 = ((float)b + 0.5f) * 2.3283064365386963e-10f;
-    // hardware log2 / sin / cos (the latter take their argument in turns): a few 1e-7 absolute,
-    // far below the quantisation of the uniforms themselves
-    const float r = __builtin_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1 < 1.0f ? u1 : 0.99999994f));
-    n0 = r * __builtin_amdgcn_cosf(u2);
-    n1 = r * __builtin_amdgcn_sinf(u2);
-}
-
 template <typename TL>
 __global__ void __launch_bounds__(256)
-channel_llr_kernel(const uint8_t *__restrict__ ref, long long ref_stride, long long frames, int n,
-                   float sigma, float gain, int plus_is_bit, int prefix_len, float prefix_llr,
-                   unsigned k0, unsigned k1, unsigned long long first_frame, float cfo, float phase0, float amp,
+channel_llr_kernel(const uint8_t *__restrict__ ref, long long ref_stride, long long frames, int n, ChannelDev ch,
                    TL *__restrict__ llr)
 {
-    const bool doppler = cfo != 0.0f || phase0 != 0.0f;  // the same for every thread
     const int quads = (n + 3) / 4;
     const long long total = frames * quads;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
         const long long f = i / quads;
         const int qd = (int)(i - f * quads);
-        const unsigned long long af = first_frame + (unsigned long long)f;
-        const Philox4 rnd = philox4x32_10((unsigned)af, (unsigned)(af >> 32), (unsigned)qd, 0u, k0, k1);
-        float z[4];
-        box_muller(rnd.x, rnd.y, z[0], z[1]);
-        box_muller(rnd.z, rnd.w, z[2], z[3]);
-        float v[4];
         const bool whole = qd * 4 + 3 < n;
         unsigned bits = 0;  // byte j = reference bit of position 4 qd + j
         if (ref) {
@@ -82,17 +44,8 @@ channel_llr_kernel(const uint8_t *__restrict__ ref, long long ref_stride, long l
                 for (int j = 0; j < 4; ++j)
                     if (qd * 4 + j < n) bits |= (unsigned)ref[f * ref_stride + qd * 4 + j] << (8 * j);
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int pos = qd * 4 + j, b = (int)((bits >> (8 * j)) & 1u);
-            float x = plus_is_bit ? (float)(2 * b - 1) : (float)(1 - 2 * b);
-            if (doppler) {
-                float turns = cfo * ((float)pos + 0.5f) + phase0;
-                turns -= __builtin_floorf(turns);  // the hardware cosine takes turns, |argument| < 256
-                x *= amp * __builtin_amdgcn_cosf(turns);
-            }
-            v[j] = pos < prefix_len ? prefix_llr : gain * (x + sigma * z[j]);
-        }
+        float v[4];
+        channel_quad(ch, ch.first_frame + (unsigned long long)f, qd, bits, v);
         bool stored = false;
         if constexpr (sizeof(TL) == 4) {  // one 16-byte store per thread
             if (whole && (n & 3) == 0) {
@@ -113,22 +66,17 @@ hipError_t launch_channel_llr(const uint8_t *ref, long long ref_stride, long lon
                               unsigned long long seed, unsigned long long first_frame, double cfo, double phase0,
                               void *llr, int llr_dtype, hipStream_t stream)
 {
-    const double pe = 3.14159265358979323846 * cfo;
-    const float amp = (float)(cfo == 0.0 ? 1.0 : sin(pe) / pe);  // sinc: loss of the integrate-and-dump filter
+    const ChannelDev ch = make_channel_dev(sigma2, gain, plus_is_bit, prefix_len, prefix_llr, seed, first_frame, cfo, phase0);
     const long long total = frames * ((n + 3) / 4);
     long long blocks = (total + 255) / 256;
     if (blocks > 16384) blocks = 16384;
     if (blocks < 1) blocks = 1;
-    const float sigma = (float)sqrt(sigma2);
-    const unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
     if (llr_dtype == LDPC_F64)
         hipLaunchKernelGGL(channel_llr_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, stream, ref, ref_stride,
-                           frames, n, sigma, (float)gain, plus_is_bit, prefix_len, (float)prefix_llr, k0, k1,
-                           first_frame, (float)cfo, (float)phase0, amp, reinterpret_cast<double *>(llr));
+                           frames, n, ch, reinterpret_cast<double *>(llr));
     else
         hipLaunchKernelGGL(channel_llr_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, stream, ref, ref_stride,
-                           frames, n, sigma, (float)gain, plus_is_bit, prefix_len, (float)prefix_llr, k0, k1,
-                           first_frame, (float)cfo, (float)phase0, amp, reinterpret_cast<float *>(llr));
+                           frames, n, ch, reinterpret_cast<float *>(llr));
     return hipGetLastError();
 }
 

@@ -26,6 +26,7 @@
 #include <cstdlib>
 
 #include "spec_common.h"
+#include "sweep_fused.h"
 
 namespace ldpc {
 
@@ -195,15 +196,22 @@ __device__ __forceinline__ void lds_put(unsigned addr, T v)
     *reinterpret_cast<__attribute__((address_space(3))) T *>((unsigned long long)addr) = v;
 }
 
-template <class C, typename T, typename TL, int F, int RL, int WPE>
+// FUSED: the channel in front and the error accounting behind run inside the kernel
+// (sweep_fused.h).  A whole frame of LLRs does not fit beside the decoder's state in LDS, so the
+// workgroup writes the LLRs of its current frames to its own slice of `scratch` ([F][n] floats, in
+// device memory but reused frame after frame, hence cache-resident) and decodes from there; llr and
+// the result arrays are unused.
+template <class C, typename T, typename TL, int F, int RL, int WPE, bool FUSED = false>
 __global__ void __launch_bounds__((LnLayout<C, T, F, RL>::THREADS)) __attribute__((amdgpu_waves_per_eu(WPE, 8)))
 lnms_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__restrict__ hard_out,
-            int *__restrict__ iters_out, uint8_t *__restrict__ conv_out, T *__restrict__ post_out)
+            int *__restrict__ iters_out, uint8_t *__restrict__ conv_out, T *__restrict__ post_out, SweepDev sp,
+            float *scratch)
 {
     typedef LnPlan<C> PL;
     typedef LnLayout<C, T, F, RL> LY;
     static_assert(PL::supported(), "code shape not supported by the layered kernel");
     static_assert(F <= 16, "the per-slot syndrome flags are one row of sixteen");
+    static_assert(!FUSED || (F <= 8 && sizeof(TL) == 4 && (C::NB * C::Z) % 4 == 0), "fused: second flag row, float LLRs, four positions per draw");
     constexpr int Z = C::Z, NB = C::NB, MB = C::MB, ST = sizeof(T);
     constexpr int n = NB * Z;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -230,6 +238,9 @@ lnms_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__r
         wave_slot_mask = ~0ull;
     }
     volatile int *slot_bad_now = slot_bad;  // polled while other waves may still be writing
+    int *slot_err = slot_bad + 8;           // fused: the slot's frame has a bit error somewhere
+    SweepAcc acc;
+    float *my_scratch = FUSED ? scratch + (size_t)blockIdx.x * (F * n) : nullptr;
 
     const long long groups = (frames + F - 1) / F;
     for (long long grp = blockIdx.x; grp < groups; grp += gridDim.x) {
@@ -237,13 +248,30 @@ lnms_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__r
         const bool active = lane_on && frame < frames;
         // loads never depend on `active`: idle lanes read a frame that exists.  The group's first
         // frame is the same for every lane (a scalar base address), the rest is a 32-bit offset.
-#ifdef LDPC_LNMS_LANE_POINTERS
-        const TL *__restrict__ lf = llr + (frame < frames ? frame : frames - 1) * n;
-        const unsigned fo = (unsigned)z;
-#else
-        const TL *__restrict__ lf = llr + grp * F * n;
-        const unsigned fo = (frame < frames ? (unsigned)f : 0u) * (unsigned)n + (unsigned)z;
-#endif
+        const TL *lf;
+        unsigned fo;
+        if constexpr (FUSED) {
+            // channel LLRs of the group's frames, four positions per draw, into this workgroup's slice
+            constexpr int QUADS = n / 4;
+            for (int i = tid; i < F * QUADS; i += LY::THREADS) {
+                const int f2 = F == 1 ? 0 : i / QUADS, qd = i - f2 * QUADS;
+                long long fr = grp * F + f2;
+                if (fr >= frames) fr = frames - 1;  // idle slot: any frame that exists
+                unsigned bits = 0;
+                if (sp.ref) bits = *reinterpret_cast<const unsigned *>(sp.ref + fr * sp.ref_stride + qd * 4) & 0x01010101u;
+                float v[4];
+                channel_quad(sp.ch, sp.ch.first_frame + (unsigned long long)fr, qd, bits, v);
+                *reinterpret_cast<float4 *>(my_scratch + f2 * n + qd * 4) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if constexpr (!LY::SINGLE) __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            lf = reinterpret_cast<const TL *>(my_scratch);
+            fo = (unsigned)f * (unsigned)n + (unsigned)z;
+        } else {
+            lf = llr + grp * F * n;
+            fo = (frame < frames ? (unsigned)f : 0u) * (unsigned)n + (unsigned)z;
+        }
 
         T A[RL > 0 ? RL : 1], B[RL > 0 ? RL : 1];
         unsigned W[RL > 0 ? RL : 1];
@@ -262,7 +290,7 @@ lnms_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__r
             }
         });
         if constexpr (!LY::SINGLE) {
-            if (tid < F) slot_bad[tid] = 0;
+            if (tid < F) { slot_bad[tid] = 0; if constexpr (FUSED) slot_err[tid] = 0; }
             __syncthreads();
         }
 
@@ -355,6 +383,35 @@ lnms_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__r
                 });
             }
             if (z == 0) { iters_out[frame] = iters; conv_out[frame] = (uint8_t)conv; }
+        };
+
+        // fused: this lane's share of the frame's bit errors against the transmitted word
+        auto count_errs = [&]() -> unsigned {
+            const uint8_t *rf = sp.ref ? sp.ref + frame * sp.ref_stride : nullptr;
+            unsigned errs = 0;
+            static_for<0, NB>([&](auto bc) {
+                if constexpr (PL::cdeg(bc) != 1) {
+                    T v;
+                    if constexpr (PL::shared(bc)) v = lds_get<T>(ln_addr<LY, PL::lds_index(bc), 0>(zb, zbP, zbPW));
+                    else v = (T)lf[fo + (unsigned)(bc * Z)] + (T)0;
+                    errs += hard_bit<1>(v) != (rf ? (unsigned)rf[bc * Z + z] : 0u);
+                }
+            });
+            static_for<0, MB>([&](auto br) {
+                if constexpr (PL::priv_pos(br) >= 0) {
+                    unsigned hb;
+                    if constexpr (PL::rdeg(br) >= 2) {
+                        T a, b;
+                        unsigned w;
+                        load_state(br, a, b, w);
+                        hb = (w >> 30) & 1u;
+                    } else {
+                        hb = hard_bit<1>(load_priv(br));
+                    }
+                    errs += hb != (rf ? (unsigned)rf[priv_index(br)] : 0u);
+                }
+            });
+            return errs;
         };
 
         // channel LLRs of the private variables the sweep needs next, requested PFS layers ahead
@@ -517,9 +574,23 @@ lnms_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__r
                 }
             });
         }
-        if (active) write_out(res_iters, res_conv);
+        if constexpr (FUSED) {
+            const unsigned errs = active ? count_errs() : 0u;
+            bool any_err;
+            if constexpr (LY::SINGLE) {
+                any_err = (__ballot(errs != 0) & slot_mask) != 0ull;
+            } else {
+                if (errs) slot_err[f] = 1;
+                __syncthreads();
+                any_err = slot_err[f] != 0;
+            }
+            if (active) acc.book(errs, any_err, z == 0, res_iters, res_conv);
+        } else {
+            if (active) write_out(res_iters, res_conv);
+        }
         if constexpr (!LY::SINGLE) __syncthreads();
     }
+    if constexpr (FUSED) acc.flush_wave(sp.counters);
 }
 
 // ------------------------------------------------------------------------------------------ host
@@ -547,8 +618,15 @@ struct LnSlots {
     static constexpr int value = DOUBLE ? 2 * F : F;
 };
 
+#ifdef LDPC_SPEC_FUSED  // second compilation of this file: the fused-sweep instantiations (see decode_spec.hip)
+constexpr bool kFused = true;
+#else
+constexpr bool kFused = false;
+#endif
+
 template <class C, typename T, typename TL, int F>
-static hipError_t launch_lnms(const ldpc_decode_config &cfg, const Launch &io, int num_cus, const char **name)
+static hipError_t launch_lnms(const ldpc_decode_config &cfg, const Launch &io, int num_cus, const char **name,
+                              const SweepDev *sp, Scratch *ws)
 {
     typedef LnConfig<C, T, F> CF;
     typedef LnLayout<C, T, F, CF::RL> LY;
@@ -556,7 +634,7 @@ static hipError_t launch_lnms(const ldpc_decode_config &cfg, const Launch &io, i
     g.rule = LDPC_RULE_LNMS; g.max_iters = cfg.max_iters; g.early_exit = cfg.early_exit;
     g.float_syndrome0 = 0; g.num_active_checks = -1; g.num_refresh_vars = -1;
     g.scale = (T)cfg.scale; g.clip_tanh_arg = (T)0; g.clip_prod = (T)0; g.clip_post = (T)0; g.offset = (T)0;
-    auto k = lnms_kernel<C, T, TL, F, CF::RL, CF::WPE>;
+    auto k = lnms_kernel<C, T, TL, F, CF::RL, CF::WPE, kFused>;
     static int static_lds = -1;  // the kernel addresses LDS from 0: it must own the whole segment
     if (static_lds < 0) {
         hipFuncAttributes attr;
@@ -565,11 +643,11 @@ static hipError_t launch_lnms(const ldpc_decode_config &cfg, const Launch &io, i
         static_lds = (int)attr.sharedSizeBytes;
     }
     if (static_lds != 0) return hipErrorInvalidConfiguration;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, LY::LDS_BYTES);
-    if (e != hipSuccess) return e;
+    hipError_t e = hipSuccess;
     static int per_cu = 0;  // resident workgroups per compute unit, as the runtime computes it
     if (per_cu == 0) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, LY::LDS_BYTES);
+        if (e != hipSuccess) return e;
         int nb = 0;
         e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(k), LY::THREADS, LY::LDS_BYTES);
         if (e != hipSuccess) return e;
@@ -580,47 +658,70 @@ static hipError_t launch_lnms(const ldpc_decode_config &cfg, const Launch &io, i
                     C::name, (int)sizeof(T), F, CF::RL, per_cu, LY::THREADS, LY::LDS_BYTES);
     }
     const long long groups = (io.frames + F - 1) / F;
-    long long grid = (long long)num_cus * (long long)per_cu * 2;
+    const long long full = (long long)num_cus * (long long)per_cu * 2;
+    long long grid = full;
     if (grid > groups) grid = groups;
     if (grid < 1) grid = 1;
+    float *scratch = nullptr;
+    if (kFused) {  // one slice of F frames' LLRs per workgroup
+        e = scratch_reserve(*ws, (size_t)F * C::NB * C::Z * sizeof(float), full, grid);
+        if (e != hipSuccess) return e;
+        scratch = reinterpret_cast<float *>(ws->ptr);
+    }
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(LY::THREADS), LY::LDS_BYTES, io.stream, g,
                        reinterpret_cast<const TL *>(io.llr), io.frames, io.hard, io.iters, io.converged,
-                       reinterpret_cast<T *>(io.posterior));
-    *name = sizeof(T) == 8 ? "spec_lnms_f64" : "spec_lnms_f32";
+                       reinterpret_cast<T *>(io.posterior), sp ? *sp : SweepDev{}, scratch);
+    *name = kFused ? (sizeof(T) == 8 ? "fused_spec_lnms_f64" : "fused_spec_lnms_f32") : (sizeof(T) == 8 ? "spec_lnms_f64" : "spec_lnms_f32");
     return hipGetLastError();
 }
 
 template <class C, int F>
 static hipError_t launch_lnms_code(const ldpc_decode_config &cfg, int compute_dtype, const Launch &io,
-                                   int num_cus, const char **name, bool *supported)
+                                   int num_cus, const char **name, bool *supported, const SweepDev *sp, Scratch *ws)
 {
     *supported = true;
-    if constexpr (LnPlan<C>::supported()) {
+    if constexpr (LnPlan<C>::supported() && (!kFused || (C::NB * C::Z) % 4 == 0)) {
         constexpr int FD = LnSlots<C, double, F>::value, FS = LnSlots<C, float, F>::value;
-        if constexpr (LnConfig<C, double, FD>::OK) {
+        if constexpr (LnConfig<C, double, FD>::OK && (!kFused || FD <= 8)) {
             if (compute_dtype == LDPC_F64) {
-                if (io.llr_dtype == LDPC_F64) return launch_lnms<C, double, double, FD>(cfg, io, num_cus, name);
-                return launch_lnms<C, double, float, FD>(cfg, io, num_cus, name);
+                if constexpr (!kFused) {
+                    if (io.llr_dtype == LDPC_F64) return launch_lnms<C, double, double, FD>(cfg, io, num_cus, name, sp, ws);
+                }
+                return launch_lnms<C, double, float, FD>(cfg, io, num_cus, name, sp, ws);
             }
         }
-        if constexpr (LnConfig<C, float, FS>::OK) {
-            if (compute_dtype == LDPC_F32 && io.llr_dtype == LDPC_F32)
-                return launch_lnms<C, float, float, FS>(cfg, io, num_cus, name);
+        if constexpr (LnConfig<C, float, FS>::OK && (!kFused || FS <= 8)) {
+            if (compute_dtype == LDPC_F32 && (kFused || io.llr_dtype == LDPC_F32))
+                return launch_lnms<C, float, float, FS>(cfg, io, num_cus, name, sp, ws);
         }
     }
     *supported = false;
     return hipSuccess;
 }
 
+#ifdef LDPC_SPEC_FUSED
+hipError_t launch_spec_lnms_fused(int spec_id, const ldpc_decode_config &cfg, int compute_dtype, const Launch &io,
+                                  const SweepDev &sp, int num_cus, Scratch &workspace, const char **name, bool *supported)
+{
+    int id = 0;
+#define LDPC_LAUNCH(CODE, SLOTS)                                                                   \
+    if (spec_id == id) return launch_lnms_code<CODE, SLOTS>(cfg, compute_dtype, io, num_cus, name, supported, &sp, &workspace); \
+    ++id;
+    LDPC_FOR_EACH_SPEC_CODE(LDPC_LAUNCH)
+#undef LDPC_LAUNCH
+    *supported = false;
+    return hipSuccess;
+}
+#else
 hipError_t launch_spec_lnms(int spec_id, const ldpc_decode_config &cfg, int compute_dtype, const Launch &io,
                             int num_cus, const char **name, bool *supported)
 {
 #ifdef LDPC_LNMS_DEV_ONLY  // development aid: instantiate one code only
-    return launch_lnms_code<LDPC_LNMS_DEV_ONLY, 1>(cfg, compute_dtype, io, num_cus, name, supported);
+    return launch_lnms_code<LDPC_LNMS_DEV_ONLY, 1>(cfg, compute_dtype, io, num_cus, name, supported, nullptr, nullptr);
 #else
     int id = 0;
 #define LDPC_LAUNCH(CODE, SLOTS)                                                                   \
-    if (spec_id == id) return launch_lnms_code<CODE, SLOTS>(cfg, compute_dtype, io, num_cus, name, supported); \
+    if (spec_id == id) return launch_lnms_code<CODE, SLOTS>(cfg, compute_dtype, io, num_cus, name, supported, nullptr, nullptr); \
     ++id;
     LDPC_FOR_EACH_SPEC_CODE(LDPC_LAUNCH)
 #undef LDPC_LAUNCH
@@ -628,5 +729,6 @@ hipError_t launch_spec_lnms(int spec_id, const ldpc_decode_config &cfg, int comp
     return hipSuccess;
 #endif
 }
+#endif
 
 }  // namespace ldpc

@@ -19,6 +19,7 @@
 #include <cstring>
 
 #include "spec_common.h"
+#include "sweep_fused.h"
 
 namespace ldpc {
 
@@ -74,10 +75,12 @@ __device__ __forceinline__ int spec_r0_checks(const unsigned char *post_b, unsig
 #define LDPC_SPEC_OCC
 #endif
 
-template <class C, typename T, typename TL, int F>
+// FUSED: the channel in front and the error accounting behind run inside the kernel (sweep_fused.h);
+// llr and the result arrays are unused, `sp` describes the channel and the counters.
+template <class C, typename T, typename TL, int F, bool FUSED = false>
 __global__ void __launch_bounds__((SpecLayout<C, T, F>::THREADS)) LDPC_SPEC_OCC
 spec_r0_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__restrict__ hard_out,
-               int *__restrict__ iters_out, uint8_t *__restrict__ conv_out, T *__restrict__ post_out)
+               int *__restrict__ iters_out, uint8_t *__restrict__ conv_out, T *__restrict__ post_out, SweepDev sp)
 {
     typedef SpecLayout<C, T, F> LY;
     typedef typename SNum<T>::Pair Pair;
@@ -99,8 +102,12 @@ spec_r0_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *
         slot_mask = (Z >= 64 ? ~0ull : ((1ull << Z) - 1ull)) << ((f * Z) & 63);
     }
 
-    constexpr bool PREFETCH = LY::SINGLE && llr_prefetch_pays<C, TL>(LY::LDS_BYTES);  // see llr_prefetch
+    static_assert(!FUSED || LY::SINGLE, "the fused variant is built for single-wave workgroups");
+    constexpr bool PREFETCH = !FUSED && LY::SINGLE && llr_prefetch_pays<C, TL>(LY::LDS_BYTES);  // see llr_prefetch
     __shared__ float stage[PREFETCH ? NB * 64 : 1];           // [NB][lane]
+    __shared__ __align__(16) float fstage[FUSED ? F * n : 1];  // fused: channel LLRs by position
+    __shared__ __align__(4) uint8_t fref[FUSED ? F * n : 4];   //        and the transmitted bits
+    SweepAcc acc;
     auto prefetch = [&](long long g2) {
         if constexpr (PREFETCH) llr_prefetch<C, F>(stage, llr, g2, frames, lane_on, f, z);
     };
@@ -111,10 +118,15 @@ spec_r0_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *
         const bool active = lane_on && frame < frames;
         T L[NB], own[NB];
         if constexpr (PREFETCH) __builtin_amdgcn_s_waitcnt(0);  // the staged LLRs have landed
+        if constexpr (FUSED) {  // one wave: its LDS operations execute in order, no barrier needed
+            sweep_stage_wave<n, F>(sp, fstage, fref, grp, frames, tid);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
         static_for<0, NB>([&](auto bc) {
             // + 0.0 turns -0.0 into +0.0: from here on "negative" is exactly "sign bit set"
             T l;
-            if constexpr (PREFETCH) l = (active ? (T)stage[bc * 64 + tid] : (T)0) + (T)0;
+            if constexpr (FUSED) l = (active ? (T)fstage[f * n + bc * Z + z] : (T)0) + (T)0;
+            else if constexpr (PREFETCH) l = (active ? (T)stage[bc * 64 + tid] : (T)0) + (T)0;
             else l = (active ? (T)llr[frame * n + bc * Z + z] : (T)0) + (T)0;
             L[bc] = l;
             own[bc] = l;  // ldpc.py:154
@@ -128,6 +140,22 @@ spec_r0_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *
             if (tid < F) slot_bad[tid] = 0;
             __syncthreads();
         }
+
+        // results of a frame: to the arrays, or (fused) into the error counters
+        auto emit = [&](int iters, int conv, bool float_check) {
+            unsigned errs = 0;
+            static_for<0, NB>([&](auto bc) {
+                const T v = own[bc];
+                const uint8_t hv = float_check ? (v == (T)0 ? 0 : (v == (T)1 ? 1 : 2)) : (uint8_t)hard_bit<0>(v);
+                if constexpr (FUSED) errs += hv != fref[f * n + bc * Z + z];
+                else {
+                    hard_out[frame * n + bc * Z + z] = hv;
+                    if (post_out) post_out[frame * n + bc * Z + z] = v;
+                }
+            });
+            if constexpr (FUSED) acc.book(errs, (__ballot(errs != 0) & slot_mask) != 0ull, z == 0, iters, conv);
+            else if (z == 0) { iters_out[frame] = iters; conv_out[frame] = (uint8_t)conv; }
+        };
 
         bool done = !active;
         int t = 0;
@@ -153,13 +181,7 @@ spec_r0_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *
             if (t == g.max_iters) { final_bad = !slot_ok; break; }
             if (g.early_exit) {
                 if (!done && slot_ok) {  // ldpc.py:165-170
-                    static_for<0, NB>([&](auto bc) {
-                        const T v = own[bc];
-                        hard_out[frame * n + bc * Z + z] =
-                            float_check ? (v == (T)0 ? 0 : (v == (T)1 ? 1 : 2)) : (uint8_t)hard_bit<0>(v);
-                        if (post_out) post_out[frame * n + bc * Z + z] = v;
-                    });
-                    if (z == 0) { iters_out[frame] = t; conv_out[frame] = 1; }
+                    emit(t, 1, float_check);
                     done = true;
                 }
                 if constexpr (LY::SINGLE) {
@@ -200,18 +222,11 @@ spec_r0_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *
             }
             if constexpr (!LY::SINGLE) __syncthreads();
         }
-        if (!done) {  // ldpc.py:210-227
-            static_for<0, NB>([&](auto bc) {
-                hard_out[frame * n + bc * Z + z] = (uint8_t)hard_bit<0>(own[bc]);
-                if (post_out) post_out[frame * n + bc * Z + z] = own[bc];
-            });
-            if (z == 0) {
-                iters_out[frame] = g.early_exit ? g.max_iters - 1 : g.max_iters;
-                conv_out[frame] = g.early_exit ? 0 : (uint8_t)!final_bad;
-            }
-        }
+        if (!done)  // ldpc.py:210-227
+            emit(g.early_exit ? g.max_iters - 1 : g.max_iters, g.early_exit ? 0 : !final_bad, false);
         if constexpr (!LY::SINGLE) __syncthreads();
     }
+    if constexpr (FUSED) acc.flush_wave(sp.counters);
 }
 
 // ------------------------------------------------------------------------------------------ R1
@@ -237,10 +252,10 @@ struct R1Layout {
     static constexpr bool QREG = C::EB * (int)sizeof(T) / 4 <= 72;  // own messages in registers
 };
 
-template <class C, typename T, typename TL, int F, bool OMS>  // OMS: the offset rule (LDPC_RULE_OMS) instead of R1's
+template <class C, typename T, typename TL, int F, bool OMS, bool FUSED = false>  // OMS: the offset rule (LDPC_RULE_OMS) instead of R1's; FUSED: as in spec_r0_kernel
 __global__ void __launch_bounds__(64) LDPC_SPEC_OCC
 spec_r1_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__restrict__ hard_out,
-               int *__restrict__ iters_out, uint8_t *__restrict__ conv_out, T *__restrict__ post_out)
+               int *__restrict__ iters_out, uint8_t *__restrict__ conv_out, T *__restrict__ post_out, SweepDev sp)
 {
     typedef R1Layout<C, T, F> LY;
     typedef typename SNum<T>::Pair Pair;
@@ -258,8 +273,11 @@ spec_r1_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *
     const unsigned zb = (unsigned)z * ST, zp = (unsigned)z * SP;
     const unsigned long long slot_mask = (Z >= 64 ? ~0ull : ((1ull << (Z & 63)) - 1ull)) << ((f * Z) & 63);
 
-    constexpr bool PREFETCH = llr_prefetch_pays<C, TL>(LY::LDS_BYTES);  // see llr_prefetch
+    constexpr bool PREFETCH = !FUSED && llr_prefetch_pays<C, TL>(LY::LDS_BYTES);  // see llr_prefetch
     __shared__ float stage[PREFETCH ? NB * 64 : 1];  // [NB][lane]
+    __shared__ __align__(16) float fstage[FUSED ? F * n : 1];  // fused: channel LLRs by position
+    __shared__ __align__(4) uint8_t fref[FUSED ? F * n : 4];   //        and the transmitted bits
+    SweepAcc acc;
     const long long groups = (frames + F - 1) / F;
     if constexpr (PREFETCH) {
         if (blockIdx.x < groups) llr_prefetch<C, F>(stage, llr, blockIdx.x, frames, lane_on, f, z);
@@ -271,12 +289,17 @@ spec_r1_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *
         T q[LY::QREG ? EB : 1];
         unsigned long long hm[NB];
         if constexpr (PREFETCH) __builtin_amdgcn_s_waitcnt(0);  // the staged LLRs have landed
+        if constexpr (FUSED) {  // one wave: its LDS operations execute in order, no barrier needed
+            sweep_stage_wave<n, F>(sp, fstage, fref, grp, frames, tid);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
         static_for<0, NB>([&](auto bc) {
             constexpr int k0 = C::col_ptr[bc], D = C::col_ptr[bc + 1] - k0;
             T l;
             // + 0: a channel value of -0.0 counts as +0.0 (sign(0) := +1, bpsk.py:227-229), and signs are
             // read from the sign bit from here on
-            if constexpr (PREFETCH) l = (active ? (T)stage[bc * 64 + tid] : (T)0) + (T)0;
+            if constexpr (FUSED) l = (active ? (T)fstage[f * n + bc * Z + z] : (T)0) + (T)0;
+            else if constexpr (PREFETCH) l = (active ? (T)stage[bc * 64 + tid] : (T)0) + (T)0;
             else l = (active ? (T)llr[frame * n + bc * Z + z] : (T)0) + (T)0;
             L[bc] = l;
             own[bc] = l;
@@ -292,11 +315,16 @@ spec_r1_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *
         }
 
         auto write_out = [&](int iters, int conv) {
+            unsigned errs = 0;
             static_for<0, NB>([&](auto bc) {
-                hard_out[frame * n + bc * Z + z] = (uint8_t)hard_bit<1>(own[bc]);
-                if (post_out) post_out[frame * n + bc * Z + z] = own[bc];
+                if constexpr (FUSED) errs += (uint8_t)hard_bit<1>(own[bc]) != fref[f * n + bc * Z + z];
+                else {
+                    hard_out[frame * n + bc * Z + z] = (uint8_t)hard_bit<1>(own[bc]);
+                    if (post_out) post_out[frame * n + bc * Z + z] = own[bc];
+                }
             });
-            if (z == 0) { iters_out[frame] = iters; conv_out[frame] = (uint8_t)conv; }
+            if constexpr (FUSED) acc.book(errs, (__ballot(errs != 0) & slot_mask) != 0ull, z == 0, iters, conv);
+            else if (z == 0) { iters_out[frame] = iters; conv_out[frame] = (uint8_t)conv; }
         };
 
         bool done = !active;
@@ -380,9 +408,19 @@ spec_r1_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *
             else write_out(g.max_iters, r1_slot_ok<C, F>(hm, slot_mask) ? 1 : 0);
         }
     }
+    if constexpr (FUSED) acc.flush_wave(sp.counters);
 }
 
 // ------------------------------------------------------------------------------------------ host
+// This file is compiled twice: as it is (the decoders behind ldpc_decode_batch) and with
+// -DLDPC_SPEC_FUSED (the same kernels with the channel in front and the error accounting behind,
+// for ldpc_sweep_batch), so that the two sets of instantiations build side by side.
+#ifdef LDPC_SPEC_FUSED
+constexpr bool kFused = true;
+#else
+constexpr bool kFused = false;
+#endif
+
 template <class C>
 static bool code_matches(int Z, int mb, int nb, int Eb, const int *er, const int *ec, const int *es)
 {
@@ -394,7 +432,8 @@ static bool code_matches(int Z, int mb, int nb, int Eb, const int *er, const int
 }
 
 template <class C, typename T, typename TL, int F>
-static hipError_t launch_spec_r0(const ldpc_decode_config &cfg, const Launch &io, int num_cus, const char **name)
+static hipError_t launch_spec_r0(const ldpc_decode_config &cfg, const Launch &io, int num_cus, const char **name,
+                                 const SweepDev *sp)
 {
     typedef SpecLayout<C, T, F> LY;
     static_assert(LY::LDS_BYTES <= 160 * 1024, "LDS limit");
@@ -402,84 +441,122 @@ static hipError_t launch_spec_r0(const ldpc_decode_config &cfg, const Launch &io
     g.rule = 0; g.max_iters = cfg.max_iters; g.early_exit = cfg.early_exit;
     g.float_syndrome0 = cfg.float_syndrome0; g.num_active_checks = -1; g.num_refresh_vars = -1;
     g.scale = (T)cfg.scale; g.clip_tanh_arg = (T)0; g.clip_prod = (T)0; g.clip_post = (T)0; g.offset = (T)0;
-    auto k = spec_r0_kernel<C, T, TL, F>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, LY::LDS_BYTES);
-    if (e != hipSuccess) return e;
-    int per_cu = 0;
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k), LY::THREADS, LY::LDS_BYTES);
-    if (e != hipSuccess) return e;
-    if (per_cu < 1) per_cu = 1;
+    auto k = spec_r0_kernel<C, T, TL, F, kFused>;
+    // attributes and occupancy of a kernel do not change: looked up once per instantiation
+    static int per_cu = 0;
+    if (per_cu == 0) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LY::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        int nb = 0;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(k), LY::THREADS, LY::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        per_cu = nb < 1 ? 1 : nb;
+    }
     const long long groups = (io.frames + F - 1) / F;
     long long grid = (long long)num_cus * (long long)per_cu * 2;
     if (grid > groups) grid = groups;
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(LY::THREADS), LY::LDS_BYTES, io.stream, g,
                        reinterpret_cast<const TL *>(io.llr), io.frames, io.hard, io.iters, io.converged,
-                       reinterpret_cast<T *>(io.posterior));
-    *name = sizeof(T) == 8 ? "spec_r0_f64" : "spec_r0_f32";
+                       reinterpret_cast<T *>(io.posterior), sp ? *sp : SweepDev{});
+    *name = kFused ? (sizeof(T) == 8 ? "fused_spec_r0_f64" : "fused_spec_r0_f32") : (sizeof(T) == 8 ? "spec_r0_f64" : "spec_r0_f32");
     return hipGetLastError();
 }
 
 template <class C, typename T, typename TL, int F, bool OMS = false>
-static hipError_t launch_spec_r1(const ldpc_decode_config &cfg, const Launch &io, int num_cus, const char **name)
+static hipError_t launch_spec_r1(const ldpc_decode_config &cfg, const Launch &io, int num_cus, const char **name,
+                                 const SweepDev *sp)
 {
     typedef R1Layout<C, T, F> LY;
+    constexpr int n = C::NB * C::Z;
     Cfg<T> g;
     g.rule = cfg.rule; g.max_iters = cfg.max_iters; g.early_exit = cfg.early_exit;
     g.float_syndrome0 = 0; g.num_active_checks = -1; g.num_refresh_vars = -1;
     g.scale = (T)cfg.scale; g.clip_tanh_arg = (T)0; g.clip_prod = (T)0; g.clip_post = (T)0; g.offset = (T)cfg.offset;
-    size_t per_cu = (160 * 1024) / LY::LDS_BYTES;
+    size_t per_cu = (160 * 1024) / (LY::LDS_BYTES + (kFused ? F * n * 5 : 0));
     if (per_cu > 32) per_cu = 32;
+    if (per_cu < 1) per_cu = 1;
     const long long groups = (io.frames + F - 1) / F;
     long long grid = (long long)num_cus * (long long)per_cu * 2;
     if (grid > groups) grid = groups;
     if (grid < 1) grid = 1;
-    auto k = spec_r1_kernel<C, T, TL, F, OMS>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, LY::LDS_BYTES);
-    if (e != hipSuccess) return e;
+    auto k = spec_r1_kernel<C, T, TL, F, OMS, kFused>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LY::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(64), LY::LDS_BYTES, io.stream, g,
                        reinterpret_cast<const TL *>(io.llr), io.frames, io.hard, io.iters, io.converged,
-                       reinterpret_cast<T *>(io.posterior));
-    *name = OMS ? (sizeof(T) == 8 ? "spec_oms_f64" : "spec_oms_f32") : (sizeof(T) == 8 ? "spec_r1_f64" : "spec_r1_f32");
+                       reinterpret_cast<T *>(io.posterior), sp ? *sp : SweepDev{});
+    if (kFused) *name = OMS ? (sizeof(T) == 8 ? "fused_spec_oms_f64" : "fused_spec_oms_f32") : (sizeof(T) == 8 ? "fused_spec_r1_f64" : "fused_spec_r1_f32");
+    else *name = OMS ? (sizeof(T) == 8 ? "spec_oms_f64" : "spec_oms_f32") : (sizeof(T) == 8 ? "spec_r1_f64" : "spec_r1_f32");
     return hipGetLastError();
 }
 
+// sp != NULL only in the fused build, where the LLR type plays no role (LLRs never exist in memory)
 template <class C, int F>
 static hipError_t launch_spec_code(const ldpc_decode_config &cfg, int compute_dtype, const Launch &io,
-                                   int num_cus, const char **name, bool *supported)
+                                   int num_cus, const char **name, bool *supported, const SweepDev *sp)
 {
     *supported = true;
-    if constexpr (C::EB <= 100) {  // flooding kernels unroll the whole base graph: small codes only
+    const bool llr64 = !kFused && io.llr_dtype == LDPC_F64, llr32 = kFused || io.llr_dtype == LDPC_F32;
+    if constexpr (C::EB <= 100 && (!kFused || SpecLayout<C, double, F>::SINGLE)) {  // flooding kernels unroll the whole base graph: small codes only
         if (cfg.rule == 0) {
             if (compute_dtype == LDPC_F64) {
-                if (io.llr_dtype == LDPC_F64) return launch_spec_r0<C, double, double, F>(cfg, io, num_cus, name);
-                return launch_spec_r0<C, double, float, F>(cfg, io, num_cus, name);
+                if constexpr (!kFused) {
+                    if (llr64) return launch_spec_r0<C, double, double, F>(cfg, io, num_cus, name, sp);
+                }
+                return launch_spec_r0<C, double, float, F>(cfg, io, num_cus, name, sp);
             }
-            if (io.llr_dtype == LDPC_F32) return launch_spec_r0<C, float, float, F>(cfg, io, num_cus, name);
+            if (llr32) return launch_spec_r0<C, float, float, F>(cfg, io, num_cus, name, sp);
         }
     }
     if constexpr (C::EB <= 100 && R1Layout<C, double, F>::THREADS == 64 && R1Layout<C, double, F>::LDS_BYTES <= 160 * 1024) {
         if (cfg.rule == 1) {
             if (compute_dtype == LDPC_F64) {
-                if (io.llr_dtype == LDPC_F64) return launch_spec_r1<C, double, double, F>(cfg, io, num_cus, name);
-                return launch_spec_r1<C, double, float, F>(cfg, io, num_cus, name);
+                if constexpr (!kFused) {
+                    if (llr64) return launch_spec_r1<C, double, double, F>(cfg, io, num_cus, name, sp);
+                }
+                return launch_spec_r1<C, double, float, F>(cfg, io, num_cus, name, sp);
             }
-            if (io.llr_dtype == LDPC_F32) return launch_spec_r1<C, float, float, F>(cfg, io, num_cus, name);
+            if (llr32) return launch_spec_r1<C, float, float, F>(cfg, io, num_cus, name, sp);
         }
         if (cfg.rule == LDPC_RULE_OMS) {
             if (compute_dtype == LDPC_F64) {
-                if (io.llr_dtype == LDPC_F64) return launch_spec_r1<C, double, double, F, true>(cfg, io, num_cus, name);
-                return launch_spec_r1<C, double, float, F, true>(cfg, io, num_cus, name);
+                if constexpr (!kFused) {
+                    if (llr64) return launch_spec_r1<C, double, double, F, true>(cfg, io, num_cus, name, sp);
+                }
+                return launch_spec_r1<C, double, float, F, true>(cfg, io, num_cus, name, sp);
             }
-            if (io.llr_dtype == LDPC_F32) return launch_spec_r1<C, float, float, F, true>(cfg, io, num_cus, name);
+            if (llr32) return launch_spec_r1<C, float, float, F, true>(cfg, io, num_cus, name, sp);
         }
     }
     *supported = false;
     return hipSuccess;
 }
 
+#ifdef LDPC_SPEC_FUSED
+// Fused sweep on the single-wave flooding kernels (rules R0, R1, OMS on the small compiled-in
+// codes); the layered rule has its own fused variant in decode_lnms.hip.
+hipError_t launch_spec_fused(int spec_id, const ldpc_decode_config &cfg, int compute_dtype, const Launch &io,
+                             const SweepDev &sp, int num_cus, Scratch &workspace, const char **name, bool *supported)
+{
+    if (cfg.rule == LDPC_RULE_LNMS)
+        return launch_spec_lnms_fused(spec_id, cfg, compute_dtype, io, sp, num_cus, workspace, name, supported);
+    int id = 0;
+#define LDPC_LAUNCH(CODE, SLOTS)                                                                   \
+    if (spec_id == id) return launch_spec_code<CODE, SLOTS>(cfg, compute_dtype, io, num_cus, name, supported, &sp); \
+    ++id;
+    LDPC_FOR_EACH_SPEC_CODE(LDPC_LAUNCH)
+#undef LDPC_LAUNCH
+    *supported = false;
+    return hipSuccess;
+}
+#else
 int spec_match(int Z, int mb, int nb, int Eb, const int *er, const int *ec, const int *es)
 {
     int id = 0;
@@ -511,12 +588,13 @@ hipError_t launch_spec(int spec_id, const ldpc_decode_config &cfg, int compute_d
     }
     int id = 0;
 #define LDPC_LAUNCH(CODE, SLOTS)                                                                   \
-    if (spec_id == id) return launch_spec_code<CODE, SLOTS>(cfg, compute_dtype, io, num_cus, name, supported); \
+    if (spec_id == id) return launch_spec_code<CODE, SLOTS>(cfg, compute_dtype, io, num_cus, name, supported, nullptr); \
     ++id;
     LDPC_FOR_EACH_SPEC_CODE(LDPC_LAUNCH)
 #undef LDPC_LAUNCH
     *supported = false;
     return hipSuccess;
 }
+#endif
 
 }  // namespace ldpc

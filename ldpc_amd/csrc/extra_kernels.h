@@ -9,4 +9,16 @@ namespace ldpc {
 hipError_t launch_bitflip(const CsrDev &code, int max_iters, int num_active_checks, const Launch &io, int num_cus,
                           const char **kernel_name, bool *supported);
 
+// encode_qc.hip: circulant-schedule encoder (replaces G @ message % 2, ldpc.py:46)
+struct EncDev {
+    int Z, n_cols, nb, k_cols, n_steps;
+    const int *info_cols;     // [k_cols] block column of each information block
+    const int *step_out;      // [n_steps] block column a step produces
+    const int *step_ptr;      // [n_steps + 1] its terms
+    const int *step_level;    // [n_steps] non-decreasing; a step reads columns of earlier levels only
+    const unsigned *terms;    // block column << 16 | shift
+};
+hipError_t launch_encode_qc(const EncDev &e, const uint8_t *msg, long long frames, uint8_t *cw, int num_cus,
+                            hipStream_t stream, bool *supported);
+
 }  // namespace ldpc

@@ -8,10 +8,12 @@
 #include <mutex>
 #include <string>
 #include <utility>
+#include <memory>
 #include <vector>
 
 #include "bp_common.h"
 #include "extra_kernels.h"
+#include "sweep_fused.h"
 
 using namespace ldpc;
 
@@ -86,7 +88,7 @@ static int noalloc_scratch(int device, Scratch *out)
 
 extern "C" const char *ldpc_last_error(void) { return g_err.c_str(); }
 extern "C" const char *ldpc_last_kernel(void) { return g_kernel; }
-extern "C" int32_t ldpc_abi_version(void) { return 2; }
+extern "C" int32_t ldpc_abi_version(void) { return 3; }
 
 extern "C" int32_t ldpc_device_count(int32_t *count)
 {
@@ -479,6 +481,136 @@ extern "C" int32_t ldpc_channel_llr_doppler(const uint8_t *ref_dev, int64_t ref_
 {
     return channel_impl(ref_dev, ref_stride, frames, n, sigma2, gain, plus_is_bit, prefix_len, prefix_llr, seed,
                         first_frame, cfo_cycles_per_symbol, phase0_cycles, llr_dev, llr_dtype, stream);
+}
+
+// ------------------------------------------------------------------------------------------ encoder
+struct ldpc_encoder {
+    int device = 0, num_cus = 0;
+    EncDev dev{};
+    int *d_ints = nullptr;  // one allocation: info_cols | step_out | step_ptr | step_level | terms
+};
+
+extern "C" int32_t ldpc_encoder_create(int32_t Z, int32_t n_cols, int32_t nb, int32_t k_cols, const int32_t *info_cols,
+                                       int32_t n_steps, const int32_t *step_out, const int32_t *step_ptr,
+                                       const int32_t *step_level, const int32_t *term_col, const int32_t *term_shift,
+                                       int32_t device, ldpc_encoder **out)
+{
+    if (!out) return fail(LDPC_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    if (Z < 1 || nb < 1 || n_cols < nb || k_cols < 1 || k_cols > nb || n_steps < 0 || n_cols > 65535)
+        return fail(LDPC_ERR_ARG, "bad encoder dimensions");
+    if (!info_cols || !step_ptr || (n_steps > 0 && (!step_out || !step_level))) return fail(LDPC_ERR_ARG, "NULL table");
+    if (Z > 1024) return fail(LDPC_ERR_UNSUPPORTED, "lifting size %d above 1024", Z);
+    // every step must read columns that are known by then: information columns or outputs of earlier levels
+    std::vector<int> known_at(n_cols, -2);  // level at which a column becomes known; -1 = information
+    for (int j = 0; j < k_cols; ++j) {
+        if (info_cols[j] < 0 || info_cols[j] >= nb || known_at[info_cols[j]] != -2) return fail(LDPC_ERR_ARG, "bad information column list");
+        known_at[info_cols[j]] = -1;
+    }
+    if (step_ptr[0] != 0) return fail(LDPC_ERR_ARG, "step_ptr must start at 0");
+    for (int s = 0; s < n_steps; ++s) {
+        if (step_ptr[s + 1] < step_ptr[s]) return fail(LDPC_ERR_ARG, "step_ptr must not decrease");
+        if (step_level[s] < 0 || (s > 0 && step_level[s] < step_level[s - 1])) return fail(LDPC_ERR_ARG, "step levels must be non-negative and non-decreasing");
+        if (step_out[s] < 0 || step_out[s] >= n_cols || known_at[step_out[s]] != -2) return fail(LDPC_ERR_ARG, "step %d writes a column that is already known", s);
+        for (int t = step_ptr[s]; t < step_ptr[s + 1]; ++t) {
+            if (!term_col || !term_shift) return fail(LDPC_ERR_ARG, "NULL table");
+            if (term_col[t] < 0 || term_col[t] >= n_cols || term_shift[t] < 0 || term_shift[t] >= Z) return fail(LDPC_ERR_ARG, "term %d out of range", t);
+            const int ka = known_at[term_col[t]];
+            if (ka == -2 || ka >= step_level[s]) return fail(LDPC_ERR_ARG, "step %d reads column %d before it is known", s, term_col[t]);
+        }
+        known_at[step_out[s]] = step_level[s];
+    }
+    for (int c = 0; c < nb; ++c)
+        if (known_at[c] == -2) return fail(LDPC_ERR_ARG, "codeword column %d is never produced", c);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(LDPC_ERR_NO_DEVICE, "no HIP device visible");
+    if (device < 0 || device >= ndev) return fail(LDPC_ERR_ARG, "device %d out of range", device);
+    HIP_TRY(hipSetDevice(device));
+    std::unique_ptr<ldpc_encoder> enc(new ldpc_encoder);
+    enc->device = device;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    enc->num_cus = prop.multiProcessorCount;
+    const int n_terms = step_ptr[n_steps];
+    std::vector<int> host;
+    host.insert(host.end(), info_cols, info_cols + k_cols);
+    host.insert(host.end(), step_out, step_out + n_steps);
+    host.insert(host.end(), step_ptr, step_ptr + n_steps + 1);
+    host.insert(host.end(), step_level, step_level + n_steps);
+    for (int t = 0; t < n_terms; ++t) host.push_back((int)(((unsigned)term_col[t] << 16) | (unsigned)term_shift[t]));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&enc->d_ints), host.size() * sizeof(int) + 16));
+    hipError_t e = hipMemcpy(enc->d_ints, host.data(), host.size() * sizeof(int), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(enc->d_ints); return fail(LDPC_ERR_HIP, "encoder tables: %s", hipGetErrorString(e)); }
+    EncDev &d = enc->dev;
+    d.Z = Z; d.n_cols = n_cols; d.nb = nb; d.k_cols = k_cols; d.n_steps = n_steps;
+    d.info_cols = enc->d_ints;
+    d.step_out = d.info_cols + k_cols;
+    d.step_ptr = d.step_out + n_steps;
+    d.step_level = d.step_ptr + n_steps + 1;
+    d.terms = reinterpret_cast<const unsigned *>(d.step_level + n_steps);
+    *out = enc.release();
+    return LDPC_OK;
+}
+
+extern "C" void ldpc_encoder_destroy(ldpc_encoder *enc)
+{
+    if (!enc) return;
+    (void)hipSetDevice(enc->device);
+    if (enc->d_ints) (void)hipFree(enc->d_ints);
+    delete enc;
+}
+
+extern "C" int32_t ldpc_encode_batch(ldpc_encoder *enc, const uint8_t *msg_dev, int64_t frames, uint8_t *cw_dev, void *stream)
+{
+    if (!enc) return fail(LDPC_ERR_ARG, "encoder is NULL");
+    if (frames < 0) return fail(LDPC_ERR_ARG, "negative frame count");
+    if (frames == 0) return LDPC_OK;
+    if (!msg_dev || !cw_dev) return fail(LDPC_ERR_ARG, "NULL buffer");
+    HIP_TRY(hipSetDevice(enc->device));
+    bool supported = false;
+    hipError_t e = launch_encode_qc(enc->dev, msg_dev, frames, cw_dev, enc->num_cus, reinterpret_cast<hipStream_t>(stream), &supported);
+    if (e != hipSuccess) return fail(LDPC_ERR_HIP, "encoder launch: %s", hipGetErrorString(e));
+    if (!supported) return fail(LDPC_ERR_UNSUPPORTED, "one frame's block columns exceed LDS");
+    return LDPC_OK;
+}
+
+extern "C" int32_t ldpc_sweep_batch(ldpc_code *c, const ldpc_decode_config *cfg, const ldpc_channel_config *ch,
+                                    const uint8_t *ref_dev, int64_t ref_stride, int64_t frames, int32_t compute_dtype,
+                                    uint64_t *counters_dev, void *stream)
+{
+    if (!c) return fail(LDPC_ERR_ARG, "code is NULL");
+    if (int rc = check_cfg(cfg)) return rc;
+    if (!ch) return fail(LDPC_ERR_ARG, "channel is NULL");
+    if (frames < 0) return fail(LDPC_ERR_ARG, "negative frame count");
+    if (compute_dtype != LDPC_F32 && compute_dtype != LDPC_F64) return fail(LDPC_ERR_ARG, "dtype must be LDPC_F32 or LDPC_F64");
+    if (!counters_dev) return fail(LDPC_ERR_ARG, "NULL buffer");
+    if (ref_dev && ref_stride != 0 && ref_stride != c->n) return fail(LDPC_ERR_ARG, "ref_stride must be 0 or n");
+    if (ref_dev && (reinterpret_cast<uintptr_t>(ref_dev) & 3u)) return fail(LDPC_ERR_ARG, "ref_dev must be 4-byte aligned");
+    if (!(ch->sigma2 >= 0.0) || ch->prefix_len < 0) return fail(LDPC_ERR_ARG, "negative noise variance or prefix length");
+    if (!(ch->cfo_cycles_per_symbol > -0.5 && ch->cfo_cycles_per_symbol < 0.5) || !(ch->phase0_cycles > -128.0 && ch->phase0_cycles < 128.0))
+        return fail(LDPC_ERR_ARG, "frequency offset must lie within half a cycle per symbol, phase within 128 cycles");
+    if (frames == 0) { g_kernel = "none"; return LDPC_OK; }
+    HIP_TRY(hipSetDevice(c->device));
+    const bool quirks = (cfg->num_active_checks >= 0 && cfg->num_active_checks < c->m) ||
+                        (cfg->num_refresh_vars >= 0 && cfg->num_refresh_vars < c->n);
+    if (c->spec_id < 0 || !c->has_qc || quirks || cfg->clip_post > 0.0)
+        return fail(LDPC_ERR_UNSUPPORTED, "the fused sweep serves compiled-in codes without loop-bound quirks or posterior clip; "
+                                          "use ldpc_channel_llr + ldpc_decode_batch + ldpc_count_errors");
+    SweepDev sp;
+    sp.ch = make_channel_dev(ch->sigma2, ch->gain, ch->plus_is_bit != 0, ch->prefix_len, ch->prefix_llr, ch->seed,
+                             ch->first_frame, ch->cfo_cycles_per_symbol, ch->phase0_cycles);
+    sp.ref = ref_dev;
+    sp.ref_stride = ref_dev ? ref_stride : 0;
+    sp.counters = reinterpret_cast<unsigned long long *>(counters_dev);
+    Launch io{nullptr, LDPC_F32, (long long)frames, nullptr, nullptr, nullptr, nullptr, reinterpret_cast<hipStream_t>(stream)};
+    bool supported = false;
+    hipError_t e = launch_spec_fused(c->spec_id, *cfg, compute_dtype, io, sp, c->num_cus, c->workspace_for(io.stream),
+                                     &g_kernel, &supported);
+    if (e != hipSuccess) return fail(LDPC_ERR_HIP, "fused sweep launch: %s", hipGetErrorString(e));
+    if (!supported)
+        return fail(LDPC_ERR_UNSUPPORTED, "no fused sweep kernel for this code, rule and arithmetic; "
+                                          "use ldpc_channel_llr + ldpc_decode_batch + ldpc_count_errors");
+    return LDPC_OK;
 }
 
 extern "C" int32_t ldpc_decode_segments(const ldpc_segment *segs, int32_t n_segs, const ldpc_decode_config *cfg,

@@ -18,6 +18,7 @@ import numpy as np
 from .codes import CompiledCode
 from .config import DecodeConfig
 from .decoder import Decoder
+from ._lib import LDPC_ERR_UNSUPPORTED, LdpcError
 
 COUNTER_NAMES = ("frames", "not_converged", "converged_wrong", "bit_errors", "iterations")
 
@@ -196,6 +197,35 @@ def count_errors(dec: Decoder, batch: DeviceBatch, stream: Optional[int] = None)
                             stream=stream)
 
 
+def sweep_fused(dec: Decoder, cw, snr_db: float, cfg: DecodeConfig, seed, counters, compute_dtype=np.float64,
+                first_frame: int = 0, llr_scale_snr_db: Optional[float] = None, cfo: float = 0.0, phase0: float = 0.0,
+                compat_prefix: bool = False, stream: Optional[int] = None) -> str:
+    """Channel, decode and error accounting of the codewords ``cw`` ([frames, n] uint8 on the device,
+    as ``make_codewords`` gives them) in one launch
+    (``ldpc_sweep_batch``): adds to ``counters`` exactly what ``noisy_batch`` + ``decode_batch`` +
+    ``count_errors`` add for the same arguments, without LLRs or hard decisions in device memory.
+    Raises ``LdpcError`` (LDPC_ERR_UNSUPPORTED) when no fused kernel serves the code and rule."""
+    import ctypes
+
+    import torch
+
+    from . import _lib, channel
+    from .config import CDecodeConfig
+
+    if stream is None:
+        stream = torch.cuda.current_stream().cuda_stream
+    sigma2, gain, plen, pval = channel.channel_parameters(snr_db, cfg, compat_prefix, llr_scale_snr_db)
+    key = int(np.random.SeedSequence(seed).generate_state(1, dtype=np.uint64)[0])
+    ch = _lib.CChannelConfig(sigma2, gain, pval, float(cfo), float(phase0), key, int(first_frame),
+                             int(cfg.plus_is_bit == 1), plen)
+    ccfg = CDecodeConfig.from_config(cfg)
+    frames, n = cw.shape
+    _lib.check(_lib.load().ldpc_sweep_batch(dec._h, ctypes.byref(ccfg), ctypes.byref(ch), cw.data_ptr(), n, frames,
+                                            1 if np.dtype(compute_dtype) == np.float64 else 0, counters.data_ptr(),
+                                            stream or None))
+    return _lib.last_kernel()
+
+
 def allreduce_counters(counters: "torch.Tensor") -> "torch.Tensor":
     """Sum the [.., 5] int64 counters over all ranks (RCCL on GPUs, gloo on CPU); the only
     collective of the multi-GPU path.  A no-op without an initialised process group."""
@@ -246,9 +276,11 @@ SWEEP_CHUNK = 1 << 14
 def ber_sweep(code: CompiledCode, G: Optional[np.ndarray], cfg: DecodeConfig, snrs_db, frames_per_point: int,
               device, compute_dtype=np.float64, seed=0, dec: Optional[Decoder] = None, batch: int = 1 << 18,
               rank: Optional[int] = None, world: Optional[int] = None, reduce: bool = True,
-              compat_prefix: bool = False):
+              compat_prefix: bool = False, fused="auto"):
     """Monte-Carlo error-rate sweep, the batched form of the reference's ``plotFrameError``
-    (ldpc.py:637-667).  The ``frames_per_point`` frames of an SNR point are numbered 0, 1, ...; rank r
+    (ldpc.py:637-667).  ``fused``: True = channel, decode and counting in one launch per batch
+    (``ldpc_sweep_batch``; an error where no fused kernel exists), False = three launches, "auto" =
+    fused where a kernel exists.  The counters are the same either way.  The ``frames_per_point`` frames of an SNR point are numbered 0, 1, ...; rank r
     of ``world`` decodes the contiguous range ``shard_range(frames_per_point, r, world)`` of them,
     counts on the device, and the counters are summed over the ranks (one all-reduce per point).
     A frame's codeword and noise depend on (seed, point, absolute frame number) only, so the summed
@@ -266,11 +298,23 @@ def ber_sweep(code: CompiledCode, G: Optional[np.ndarray], cfg: DecodeConfig, sn
         while pos < b:
             # one launch: the part of [pos, b) that lies in the next `per_launch`-aligned window
             end = min(b, (pos // per_launch + 1) * per_launch)
-            bt = make_batch_range(code, G, pos, end, frames_per_point, float(snr), cfg, seed=[seed, si], device=device,
-                                  compat_prefix=compat_prefix)
-            decode_batch(dec, bt, cfg, compute_dtype=compute_dtype)
-            count_errors(dec, bt)
-            total += bt.counters
+            done = False
+            if fused:
+                cw = codewords_range(code, G, pos, end, frames_per_point, [seed, si], device)
+                try:
+                    sweep_fused(dec, cw, float(snr), cfg, [seed, si], total, compute_dtype=compute_dtype,
+                                first_frame=pos, compat_prefix=compat_prefix)
+                    done = True
+                except LdpcError as e:
+                    if fused is True or e.code != LDPC_ERR_UNSUPPORTED:
+                        raise
+                    fused = False
+            if not done:
+                bt = make_batch_range(code, G, pos, end, frames_per_point, float(snr), cfg, seed=[seed, si], device=device,
+                                      compat_prefix=compat_prefix)
+                decode_batch(dec, bt, cfg, compute_dtype=compute_dtype)
+                count_errors(dec, bt)
+                total += bt.counters
             pos = end
         if reduce:
             allreduce_counters(total)
@@ -281,12 +325,9 @@ def ber_sweep(code: CompiledCode, G: Optional[np.ndarray], cfg: DecodeConfig, sn
     return out
 
 
-def make_batch_range(code: CompiledCode, G, first: int, last: int, total: int, snr_db: float, cfg: DecodeConfig,
-                     seed, device, llr_dtype=None, compat_prefix: bool = False) -> DeviceBatch:
-    """The frames [first, last) of a sweep point of ``total`` frames.  Codewords are drawn per
-    ``SWEEP_CHUNK``-aligned chunk of absolute frame numbers (seed + [chunk]), noise comes from the
-    library's channel kernel keyed by the absolute frame number: the result does not depend on how
-    the point is cut into ranges."""
+def codewords_range(code: CompiledCode, G, first: int, last: int, total: int, seed, device):
+    """Codewords of the frames [first, last) of a sweep point of ``total`` frames, drawn per
+    ``SWEEP_CHUNK``-aligned chunk of absolute frame numbers (seed + [chunk])."""
     import torch
 
     seed = list(np.atleast_1d(seed))
@@ -296,6 +337,15 @@ def make_batch_range(code: CompiledCode, G, first: int, last: int, total: int, s
         c1 = min(total, c0 + SWEEP_CHUNK)
         cw = make_codewords(code, G, c1 - c0, seed + [c], device)
         parts.append(cw[max(first, c0) - c0:min(last, c1) - c0])
-    cw = parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
+    return parts[0] if len(parts) == 1 else torch.cat(parts, dim=0).contiguous()
+
+
+def make_batch_range(code: CompiledCode, G, first: int, last: int, total: int, snr_db: float, cfg: DecodeConfig,
+                     seed, device, llr_dtype=None, compat_prefix: bool = False) -> DeviceBatch:
+    """The frames [first, last) of a sweep point of ``total`` frames.  Codewords come from
+    ``codewords_range``, noise from the library's channel kernel keyed by the absolute frame number:
+    the result does not depend on how the point is cut into ranges."""
+    seed = list(np.atleast_1d(seed))
+    cw = codewords_range(code, G, first, last, total, seed, device)
     return noisy_batch(code, cw, snr_db, cfg, seed, device, llr_dtype=llr_dtype, first_frame=first,
                        compat_prefix=compat_prefix)

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in names:
         assert hasattr(lib, name), name
     assert sorted(_lib.SYMBOLS) == names
-    assert lib.ldpc_abi_version() == 2
+    assert lib.ldpc_abi_version() == 3
 
 
 def test_config_struct_layout_matches_header():

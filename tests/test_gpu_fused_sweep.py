@@ -1,0 +1,98 @@
+"""ldpc_sweep_batch: channel -> decode -> error accounting in one launch (the body of the
+reference's Monte-Carlo loop, /root/reference/ldpc.py:644-667) against the same three steps as
+three launches (ldpc_channel_llr, ldpc_decode_batch, ldpc_count_errors) on the same seed: the five
+counters must be equal, not close - both paths draw the same noise and run the same arithmetic."""
+import numpy as np
+import pytest
+
+from ldpc_amd import _lib, codes, config
+
+pytestmark = pytest.mark.gpu
+
+#: (code, rule, Es/N0 dB, frames): operating points where some frames fail and some converge
+CASES = [("ccsds512", "R0", 0.5, 40_000), ("ccsds512", "R1", -0.75, 40_000), ("ccsds512", "OMS", -0.75, 20_000),
+         ("wifi648", "R0", 6.0, 20_001), ("wifi648", "R1", -1.0, 20_001), ("nr_bg2_z40", "LNMS", -6.0, 3_001),
+         ("nr_bg2_z40_r1400", "LNMS", -4.5, 3_000), ("nr_bg1_z384", "LNMS", -3.75, 1_025), ("wifi648", "LNMS", -1.0, 10_000)]
+
+
+def _both(code, G, cfg, snr, frames, dtype, dev, **kw):
+    import torch
+    from ldpc_amd import sweep
+    from ldpc_amd.decoder import Decoder
+    dec = Decoder(code)
+    cw = sweep.make_codewords(code, G, frames, [21], dev)
+    fused = torch.zeros((5,), dtype=torch.int64, device=dev)
+    kernel = sweep.sweep_fused(dec, cw, snr, cfg, [22], fused, compute_dtype=dtype, first_frame=7, **kw)
+    bt = sweep.noisy_batch(code, cw, snr, cfg, [22], dev, first_frame=7, **kw)
+    sweep.decode_batch(dec, bt, cfg, compute_dtype=dtype)
+    sweep.count_errors(dec, bt)
+    torch.cuda.synchronize()
+    return kernel, fused.cpu().numpy(), bt.counters.cpu().numpy()
+
+
+@pytest.mark.parametrize("name,rule,snr,frames", CASES, ids=[f"{c[0]}-{c[1]}" for c in CASES])
+def test_fused_counters_equal_three_launches(name, rule, snr, frames):
+    import torch
+    dev = torch.device("cuda", 0)
+    code = codes.load_packaged(name)
+    G = codes.load_packaged_generator(name) if name in ("ccsds512", "wifi648") else None
+    for dtype in (np.float64, np.float32):
+        for cfg in (config.PRESETS[rule], config.PRESETS[rule].with_(max_iters=6, early_exit=False)):
+            kernel, fused, three = _both(code, G, cfg, snr, frames, dtype, dev)
+            assert kernel.startswith("fused_spec_"), kernel
+            assert fused.tolist() == three.tolist(), (kernel, cfg.early_exit, fused, three)
+            assert fused[0] == frames
+            if cfg.early_exit and (name, rule) != ("wifi648", "R0"):   # R0 never converges on the 802.11n code
+                assert 0 < fused[1] < frames, fused        # the batch straddles the waterfall
+
+
+def test_fused_with_prefix_doppler_and_all_zero_word():
+    import torch
+    from ldpc_amd import channel, sweep
+    from ldpc_amd.decoder import Decoder
+    dev = torch.device("cuda", 0)
+    code = codes.load_packaged("ccsds512")
+    G = codes.load_packaged_generator("ccsds512")
+    # the reference's overwritten prefix (bpsk.py:163) and a carrier offset
+    for kw in (dict(compat_prefix=True), dict(cfo=channel.doppler_cfo(4000.0, compensated=0.999), phase0=0.05)):
+        kernel, fused, three = _both(code, G, config.R1, 1.0, 9_999, np.float64, dev, **kw)
+        assert fused.tolist() == three.tolist(), (kw, fused, three)
+    # all-zero codeword: ref_dev = NULL against an explicit array of zeros
+    dec = Decoder(code)
+    zeros = torch.zeros((5000, code.n), dtype=torch.uint8, device=dev)
+    a = torch.zeros((5,), dtype=torch.int64, device=dev)
+    b = torch.zeros((5,), dtype=torch.int64, device=dev)
+    sweep.sweep_fused(dec, zeros, 0.0, config.R1, [3], a, compute_dtype=np.float32)
+    import ctypes
+    from ldpc_amd.config import CDecodeConfig
+    sigma2, gain, plen, pval = channel.channel_parameters(0.0, config.R1)
+    key = int(np.random.SeedSequence([3]).generate_state(1, dtype=np.uint64)[0])
+    ch = _lib.CChannelConfig(sigma2, gain, pval, 0.0, 0.0, key, 0, 0, plen)
+    ccfg = CDecodeConfig.from_config(config.R1)
+    _lib.check(_lib.load().ldpc_sweep_batch(dec._h, ctypes.byref(ccfg), ctypes.byref(ch), None, 0, 5000, 0,
+                                            b.data_ptr(), torch.cuda.current_stream().cuda_stream or None))
+    torch.cuda.synchronize()
+    assert a.cpu().numpy().tolist() == b.cpu().numpy().tolist() and a[0] == 5000 and a[1] > 0
+
+
+def test_ber_sweep_fused_equals_unfused_and_unsupported_falls_back():
+    import torch
+    from ldpc_amd import sweep
+    dev = torch.device("cuda", 0)
+    code = codes.load_packaged("ccsds512")
+    G = codes.load_packaged_generator("ccsds512")
+    snrs = [0.0, 1.0]
+    a = sweep.ber_sweep(code, G, config.R0, snrs, 100_000, dev, np.float64, seed=4, fused=True)
+    b = sweep.ber_sweep(code, G, config.R0, snrs, 100_000, dev, np.float64, seed=4, fused=False)
+    assert a == b
+    # the sum-product rules have no fused kernel: "auto" falls back, True raises
+    c = sweep.ber_sweep(code, G, config.R3, [1.0], 5_000, dev, np.float32, seed=4)
+    d = sweep.ber_sweep(code, G, config.R3, [1.0], 5_000, dev, np.float32, seed=4, fused=False)
+    assert c == d
+    with pytest.raises(_lib.LdpcError) as ei:
+        sweep.ber_sweep(code, G, config.R3, [1.0], 5_000, dev, np.float32, seed=4, fused=True)
+    assert ei.value.code == _lib.LDPC_ERR_UNSUPPORTED
+    # a matrix that is not compiled in
+    other = codes.compile_code(np.roll(code.dense(), 1, axis=1), "rolled")
+    with pytest.raises(_lib.LdpcError):
+        sweep.ber_sweep(other, None, config.R0, [1.0], 1_000, dev, np.float32, seed=4, fused=True)
