@@ -158,12 +158,18 @@ def schedule_for(code: CompiledCode, G: Optional[np.ndarray] = None) -> Optional
     pairs = {}
     for r, c in zip(code.qc.edge_row.tolist(), code.qc.edge_col.tolist()):
         pairs[(r, c)] = pairs.get((r, c), 0) + 1
+    candidates = []
     if max(pairs.values()) == 1:      # blocks that are sums of two circulants cannot be substituted through
-        s = parity_structure_schedule(code.qc)
-        if s is not None:
-            return s
+        candidates.append(parity_structure_schedule(code.qc))
     if G is not None:
-        return generator_schedule(G, code.qc.Z)
+        candidates.append(generator_schedule(G, code.qc.Z))
+    for s in candidates:
+        if s is None or s.n != code.n:
+            continue
+        # a schedule is only handed out if what it produces are codewords
+        msgs = np.random.default_rng(5).integers(0, 2, size=(4, s.k), dtype=np.uint8)
+        if all(code.is_codeword(c) for c in s.run_host(msgs)):
+            return s
     return None
 
 

@@ -36,24 +36,29 @@ class DeviceBatch:
 def make_codewords(code: CompiledCode, G, frames: int, seed, device) -> "torch.Tensor":
     """[frames, n] uint8 codewords of random messages on the device: all-zero if ``G`` is None, else
     ``G`` is a k x n generator matrix (msg @ G mod 2, the reference's ldpc.py:46 with G transposed)
-    or a callable encoder with attribute ``k``."""
+    or a callable encoder with attribute ``k``: ``encoder.DeviceEncoder`` (ldpc_encode_batch, messages
+    drawn on the device) or a host function on numpy arrays."""
     import torch
 
     n = code.n
     if G is None:
         return torch.zeros((frames, n), dtype=torch.uint8, device=device)
     cw = torch.empty((frames, n), dtype=torch.uint8, device=device)
-    if callable(G):  # structured encoder: a device encoder (takes and returns tensors) or a host one
-        on_device = getattr(G, "on_device", False)
+    if callable(G) and getattr(G, "on_device", False):  # device encoder (encoder.DeviceEncoder): messages drawn on the device
+        gen = torch.Generator(device=device)
+        gen.manual_seed(int(np.random.SeedSequence(seed).generate_state(1)[0]))
+        step = max(1, (1 << 28) // max(n, 1))
+        for a in range(0, frames, step):
+            b = min(frames, a + step)
+            cw[a:b] = G(torch.randint(0, 2, (b - a, G.k), generator=gen, device=device, dtype=torch.uint8))
+        return cw
+    if callable(G):  # structured encoder on the host
         host_rng = np.random.default_rng(np.random.SeedSequence(seed).generate_state(2))
         step = max(1, (1 << 26) // max(n, 1))
         for a in range(0, frames, step):
             b = min(frames, a + step)
             msg = host_rng.integers(0, 2, size=(b - a, G.k), dtype=np.uint8)
-            if on_device:
-                cw[a:b] = G(torch.as_tensor(msg, device=device))
-            else:
-                cw[a:b] = torch.as_tensor(G(msg), device=device)
+            cw[a:b] = torch.as_tensor(G(msg), device=device)
         return cw
     gen = torch.Generator(device=device)
     gen.manual_seed(int(np.random.SeedSequence(seed).generate_state(1)[0]))

@@ -1,0 +1,106 @@
+"""The circulant-schedule encoder (ldpc_encode_batch), which stands in for the reference's dense
+generator product `numpy.dot(self.G, message) % 2` (/root/reference/ldpc.py:46, G from
+pyldpc.coding_matrix, ldpc.py:369).  Nothing in the reference pins a generator (PARITY UNPINNED:
+pyldpc is absent and unversioned), so the checks are: every output is a codeword of the reference's
+matrix, the message sits unchanged in the information positions, the map is linear, and it equals
+the generator the reference's own CCSDS file carries (LDPC_CCSDS_256.mat, key "G") and this build's
+host encoder of the 5G-structured table."""
+import numpy as np
+import pytest
+
+from ldpc_amd import codes, encoder, nr_bg1
+
+NAMES = ["ccsds512", "wifi648", "nr_bg2_z40", "nr_bg1_z384"]
+
+
+def _schedule(name):
+    code = codes.load_packaged(name)
+    G = codes.load_packaged_generator(name) if name in ("ccsds512", "wifi648") else None
+    return code, G, encoder.schedule_for(code, G)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_schedules_produce_codewords(name):
+    code, G, s = _schedule(name)
+    assert s is not None and s.n == code.n and s.k == code.n - code.m
+    rng = np.random.default_rng(1)
+    msgs = rng.integers(0, 2, size=(6, s.k), dtype=np.uint8)
+    cw = s.run_host(msgs)
+    assert all(code.is_codeword(c) for c in cw)
+    # systematic: information block j of the message is block column info_cols[j] of the codeword
+    Z = s.Z
+    for j, c in enumerate(s.info_cols):
+        assert np.array_equal(cw[:, c * Z:(c + 1) * Z], msgs[:, j * Z:(j + 1) * Z])
+    # linear
+    assert np.array_equal(s.run_host(msgs[:1] ^ msgs[1:2]), cw[:1] ^ cw[1:2])
+    # every step reads only columns of lower levels
+    known = {c: -1 for c in s.info_cols}
+    for out, lv, terms in zip(s.step_out, s.step_level, s.step_terms):
+        assert all(known[c] < lv for c, _ in terms)
+        known[out] = lv
+    if name == "ccsds512":      # the generator in the reference's own .mat file
+        assert np.array_equal(cw, codes.encode(G, msgs))
+    if name == "nr_bg1_z384":   # this build's host encoder of the same table
+        assert np.array_equal(cw, nr_bg1.encode(code.qc, msgs))
+
+
+def test_no_schedule_where_the_structure_is_missing():
+    # the row-truncated 5G matrix of channel.py:35 has unconstrained columns: no parity structure
+    code = codes.load_packaged("nr_bg2_z40_r1400")
+    assert encoder.schedule_for(code) is None
+    # a generator that is not block-circulant
+    c2 = codes.load_packaged("wifi648")
+    assert encoder.generator_schedule(codes.load_packaged_generator("wifi648"), c2.qc.Z) is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES)
+def test_device_encoder_equals_host_schedule(name):
+    import torch
+    dev = torch.device("cuda", 0)
+    code, G, s = _schedule(name)
+    enc = encoder.DeviceEncoder(s)
+    rng = np.random.default_rng(2)
+    for frames in (1, 7, 300 if code.n > 4096 else 5000):
+        msgs = rng.integers(0, 2, size=(frames, s.k), dtype=np.uint8)
+        cw = enc(torch.as_tensor(msgs, device=dev)).cpu().numpy()
+        assert np.array_equal(cw, s.run_host(msgs)), (name, frames)
+    assert enc(torch.zeros((0, s.k), dtype=torch.uint8, device=dev)).shape == (0, code.n)
+
+
+@pytest.mark.gpu
+def test_encoder_feeds_the_sweep_and_rejects_bad_schedules():
+    import ctypes
+    import torch
+    from ldpc_amd import _lib, config, sweep
+    dev = torch.device("cuda", 0)
+    code, G, s = _schedule("nr_bg1_z384")
+    enc = encoder.device_encoder(code)
+    cw = sweep.make_codewords(code, enc, 700, [5], dev)
+    assert cw.shape == (700, code.n) and cw.any()
+    host = cw.cpu().numpy()
+    assert all(code.is_codeword(c) for c in host[:20])
+    # random codewords decode like the all-zero word (the rule is symmetric; the noise realisations differ
+    # in effect, so the agreement is statistical): same convergence, mean sweep count within 3 %
+    out = sweep.ber_sweep(code, enc, config.LNMS, [-3.0], 2000, dev, np.float32, seed=8)[0]
+    zero = sweep.ber_sweep(code, None, config.LNMS, [-3.0], 2000, dev, np.float32, seed=8)[0]
+    assert out["not_converged"] == zero["not_converged"] == 0 and out["bit_errors"] == 0
+    assert abs(out["iterations"] - zero["iterations"]) < 0.03 * zero["iterations"]
+    # a step that reads a column of its own level is refused
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    i32 = lambda a: np.asarray(a, np.int32)
+    info, outs, ptr, lv, tc, ts = i32([0]), i32([1, 2]), i32([0, 1, 2]), i32([0, 0]), i32([0, 1]), i32([0, 0])
+    rc = lib.ldpc_encoder_create(4, 3, 3, 1, info.ctypes.data, 2, outs.ctypes.data, ptr.ctypes.data, lv.ctypes.data,
+                                 tc.ctypes.data, ts.ctypes.data, 0, ctypes.byref(h))
+    assert rc == _lib.LDPC_ERR_ARG and b"before it is known" in lib.ldpc_last_error()
+    lv = i32([0, 1])
+    rc = lib.ldpc_encoder_create(4, 3, 3, 1, info.ctypes.data, 2, outs.ctypes.data, ptr.ctypes.data, lv.ctypes.data,
+                                 tc.ctypes.data, ts.ctypes.data, 0, ctypes.byref(h))
+    assert rc == 0
+    msg = torch.tensor([[1, 0, 1, 1]], dtype=torch.uint8, device=dev)
+    out = torch.empty((1, 12), dtype=torch.uint8, device=dev)
+    assert lib.ldpc_encode_batch(h, msg.data_ptr(), 1, out.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    assert out.cpu().numpy().tolist() == [[1, 0, 1, 1] * 3]
+    lib.ldpc_encoder_destroy(h)
