@@ -327,7 +327,7 @@ def other_workloads(head, args, torch, dist, device, world, rank):
     res = {}
 
     def run(label, runner, rule, dtype, snr, early, frames):
-        r, b, _ = runner.run(rule, dtype, snr, early, frames, 3, 1, max_iters=args.max_iters, seed=8 + len(label))
+        r, b, _ = runner.run(rule, dtype, snr, early, frames, 3, 2, max_iters=args.max_iters, seed=8 + len(label))
         res[label] = {"gbit_s": r["value"], "mean_iters": r["mean_iters"], "fer": r["fer"], "ber": r["ber"],
                       "frames": frames, "code": runner.name, "rule": rule, "dtype": dtype, "es_n0_db": snr,
                       "early_exit": early, "kernel": r["kernel"]}
@@ -362,6 +362,75 @@ def other_workloads(head, args, torch, dist, device, world, rank):
                                ("BG2_Z40_R3_f32_fixed_10", "R3", "f32")]:
         run(label, bg2, rule, dtype, -2.0, False, 32768)
     run("BG2_Z40_R1_f32_es_n0_-4dB", bg2, "R1", "f32", -4.0, True, 32768)
+    res.update(link_workloads(head, bg2, args, torch, dist, device, world, rank))
+    return res
+
+
+def link_workloads(head, bg2, args, torch, dist, device, world, rank):
+    """The steps around the decoder: the Monte-Carlo loop body as one launch (ldpc_sweep_batch) beside
+    the same work as three launches, the mixed CCSDS + 5G sum-product batch under the Doppler-shifted
+    channel (BASELINE configuration 5), the device encoder and 5G rate recovery."""
+    from ldpc_amd import channel, config, encoder, nr_rate_match, sweep
+    res = {}
+    code, dec = head.code, head.dec
+    frames = min(args.frames, 1 << 19)
+    for label, rule, dtype, snr in (("sweep_R0_f64_es_n0_1dB", "R0", np.float64, 1.0), ("sweep_R1_f32_es_n0_1dB", "R1", np.float32, 1.0)):
+        cfg = config.PRESETS[rule].with_(max_iters=args.max_iters)
+        cw = sweep.make_codewords(code, head.G, frames, [31, rank], device)
+        ctr = torch.zeros((5,), dtype=torch.int64, device=device)
+
+        def fused():
+            sweep.sweep_fused(dec, cw, snr, cfg, [32, rank], ctr, compute_dtype=dtype)
+
+        def three():
+            bt = sweep.noisy_batch(code, cw, snr, cfg, [32, rank], device)
+            sweep.decode_batch(dec, bt, cfg, compute_dtype=dtype)
+            sweep.count_errors(dec, bt)
+
+        w1, _ = timed_steps(fused, 3, 2, torch, dist, world)
+        w3, _ = timed_steps(three, 3, 2, torch, dist, world)
+        res[label] = {"fused_gbit_s": frames * world * 3 * head.k / w1 / 1e9, "three_launch_gbit_s": frames * world * 3 * head.k / w3 / 1e9,
+                      "frames": frames, "code": code.name, "rule": rule, "es_n0_db": snr, "early_exit": True,
+                      "hbm_bytes_per_frame_fused": code.n, "hbm_bytes_per_frame_three_launches": 11 * code.n + 10}
+        del cw
+    # configuration 5: CCSDS and 5G frames of one link in one call, sum-product rule R3, Doppler-shifted BPSK
+    cfg = config.R3.with_(max_iters=args.max_iters)
+    cfo = channel.doppler_cfo(4000.0, compensated=0.999)
+    parts = []
+    for runner, fr, snr in ((head, 1 << 16, 1.0), (bg2, 1 << 13, -4.0)):
+        cwp = sweep.make_codewords(runner.code, runner.G, fr, [33, rank], device)
+        parts.append((runner.dec, sweep.noisy_batch(runner.code, cwp, snr, cfg, [34, rank], device, cfo=cfo)))
+    ctr = torch.zeros((5,), dtype=torch.int64, device=device)
+    step = lambda: sweep.decode_mixed(parts, cfg, compute_dtype=np.float32, counters=ctr)
+    w, _ = timed_steps(step, 3, 2, torch, dist, world)
+    info_bits = (1 << 16) * head.k + (1 << 13) * bg2.k
+    ctr.zero_()
+    step()
+    torch.cuda.synchronize()
+    st = sweep.summarize(ctr.cpu().numpy(), 1)
+    res["mixed_ccsds_bg2_R3_f32_doppler"] = {"gbit_s": info_bits * world * 3 / w / 1e9, "frames": [1 << 16, 1 << 13],
+                                             "codes": [head.name, bg2.name], "rule": "R3", "dtype": "f32",
+                                             "cfo_cycles_per_symbol": cfo, "es_n0_db": [1.0, -4.0], "fer": st["fer"],
+                                             "mean_iters": st["mean_iters"], "early_exit": True}
+    del parts
+    # encoder and rate recovery of the 5G-structured table at Z = 384 (HBM-bound byte work)
+    from ldpc_amd import codes
+    bg1 = codes.load_packaged("nr_bg1_z384")
+    enc = encoder.device_encoder(bg1)
+    fr = 16384
+    msg = torch.randint(0, 2, (fr, enc.k), device=device, dtype=torch.uint8)
+    cwb = torch.empty((fr, enc.n), dtype=torch.uint8, device=device)
+    stream = torch.cuda.current_stream().cuda_stream
+    w, _ = timed_steps(lambda: enc.encode_ptr(msg.data_ptr(), fr, cwb.data_ptr(), stream), 3, 2, torch, dist, world)
+    res["encode_bg1_z384"] = {"gbit_s": fr * enc.k * world * 3 / w / 1e9, "gb_s": fr * (enc.k + enc.n) * world * 3 / w / 1e9,
+                              "frames": fr, "bytes_per_frame": enc.k + enc.n}
+    r = nr_rate_match.RateMatch(1, 384, 2 * 8448)
+    llr = torch.randn((fr, r.E), device=device, dtype=torch.float32)
+    out = torch.empty((fr, r.n_active()), device=device, dtype=torch.float32)
+    w, _ = timed_steps(lambda: r.recover_device(llr, r.n_active(), into=None, out_dtype=torch.float32), 3, 2, torch, dist, world)
+    res["rate_recover_bg1_rate_half"] = {"gb_s": fr * 4 * (r.E + r.n_active()) * world * 3 / w / 1e9, "frames": fr,
+                                         "bytes_per_frame": 4 * (r.E + r.n_active()), "E": r.E, "n_active": r.n_active()}
+    del out
     return res
 
 

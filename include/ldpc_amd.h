@@ -260,6 +260,38 @@ void ldpc_encoder_destroy(ldpc_encoder *enc);
 int32_t ldpc_encode_batch(ldpc_encoder *enc, const uint8_t *msg_dev, int64_t frames, uint8_t *cw_dev, void *stream);
 
 /*
+ * 5G NR rate matching (3GPP TS 38.212 section 5.4.2: bit selection from the circular buffer, bit
+ * interleaving) and its inverse on LLRs.  The reference fakes both ends with constants: the matrix
+ * cut to its first 1400 rows (/root/reference/channel.py:35: the extension parity bits that were
+ * never sent) and the first 80 LLRs overwritten (bpsk.py:163, channel.py:412: the 2 Z punctured
+ * systematic bits of a Z = 40 code).  Codeword position offset + d is position d of the circular
+ * buffer (0 <= d < n_cb, offset = 2 Z); buffer positions [filler_begin, filler_end) are filler
+ * bits (known zeros, never sent); e_k is the k-th position met walking from k0, wrapping, skipping
+ * fillers (k < E); f_{i + j Qm} = e_{i E/Qm + j} goes over the air (Qm = 1: no interleaving).
+ * ldpc_amd/nr_rate_match.py derives the numbers (base graph and lifting size selection, k0 per
+ * redundancy version, filler count, active rows of the matrix).
+ *   ldpc_rate_match    cw_dev [frames, cw_stride] codeword bytes -> out_dev [frames, E] bytes (order f)
+ *   ldpc_rate_recover  llr_dev [frames, E] (order f) -> out_dev [frames, n_out] LLRs of codeword
+ *                      positions 0 .. n_out-1: 0 where nothing was sent, the sum over all laps where a
+ *                      position was sent more than once, filler_llr at fillers; accumulate != 0 adds to
+ *                      what out_dev holds (soft combining of retransmissions; fillers are set)
+ */
+typedef struct ldpc_rate_match_config {
+    int32_t n_cb;          /* circular buffer length */
+    int32_t k0;            /* starting position of the redundancy version */
+    int32_t filler_begin;  /* in buffer positions */
+    int32_t filler_end;
+    int32_t E;             /* transmitted bits per frame */
+    int32_t Qm;            /* bits per modulation symbol; 1 = no interleaving */
+    int32_t offset;        /* codeword position of buffer position 0 (2 Z) */
+    int32_t n_out;         /* ldpc_rate_recover: codeword positions the decoder uses */
+} ldpc_rate_match_config;
+int32_t ldpc_rate_match(const ldpc_rate_match_config *cfg, const uint8_t *cw_dev, int64_t cw_stride, int64_t frames,
+                        uint8_t *out_dev, void *stream);
+int32_t ldpc_rate_recover(const ldpc_rate_match_config *cfg, const void *llr_dev, int32_t llr_dtype, int64_t frames,
+                          double filler_llr, int32_t accumulate, void *out_dev, int32_t out_dtype, void *stream);
+
+/*
  * Channel -> decode -> error accounting of `frames` frames in ONE launch: the body of the
  * reference's Monte-Carlo loop (/root/reference/ldpc.py:644-667: encode + noise, ldpc.py:651 -> 52,
  * decode, ldpc.py:654, count, ldpc.py:660-662) without LLRs or hard decisions ever reaching device

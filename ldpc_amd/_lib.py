@@ -20,7 +20,7 @@ KERNEL_AUTO, KERNEL_CSR, KERNEL_QC = 0, 1, 2
 #: every symbol include/ldpc_amd.h declares
 SYMBOLS = ["ldpc_last_error", "ldpc_abi_version", "ldpc_device_count", "ldpc_code_create_csr",
            "ldpc_code_attach_qc", "ldpc_code_destroy", "ldpc_code_info", "ldpc_decode_batch",
-           "ldpc_decode_batch_host", "ldpc_decode_batch_noalloc", "ldpc_noalloc_scratch_bytes", "ldpc_count_errors", "ldpc_channel_llr", "ldpc_channel_llr_doppler", "ldpc_decode_segments", "ldpc_sweep_batch", "ldpc_encoder_create", "ldpc_encoder_destroy", "ldpc_encode_batch",
+           "ldpc_decode_batch_host", "ldpc_decode_batch_noalloc", "ldpc_noalloc_scratch_bytes", "ldpc_count_errors", "ldpc_channel_llr", "ldpc_channel_llr_doppler", "ldpc_decode_segments", "ldpc_sweep_batch", "ldpc_encoder_create", "ldpc_encoder_destroy", "ldpc_encode_batch", "ldpc_rate_match", "ldpc_rate_recover",
            "ldpc_last_kernel"]
 
 
@@ -39,6 +39,12 @@ class CChannelConfig(ctypes.Structure):
                 ("cfo_cycles_per_symbol", ctypes.c_double), ("phase0_cycles", ctypes.c_double),
                 ("seed", ctypes.c_uint64), ("first_frame", ctypes.c_uint64), ("plus_is_bit", ctypes.c_int32),
                 ("prefix_len", ctypes.c_int32)]
+
+
+class CRateMatchConfig(ctypes.Structure):
+    """Binary image of ``ldpc_rate_match_config`` (include/ldpc_amd.h)."""
+
+    _fields_ = [(k, ctypes.c_int32) for k in ("n_cb", "k0", "filler_begin", "filler_end", "E", "Qm", "offset", "n_out")]
 
 
 class LdpcError(RuntimeError):
@@ -121,6 +127,10 @@ def load() -> ctypes.CDLL:
     lib.ldpc_encoder_destroy.argtypes = [vp]
     lib.ldpc_encode_batch.restype = i32
     lib.ldpc_encode_batch.argtypes = [vp, vp, i64, vp, vp]
+    lib.ldpc_rate_match.restype = i32
+    lib.ldpc_rate_match.argtypes = [ctypes.POINTER(CRateMatchConfig), vp, i64, i64, vp, vp]
+    lib.ldpc_rate_recover.restype = i32
+    lib.ldpc_rate_recover.argtypes = [ctypes.POINTER(CRateMatchConfig), vp, i32, i64, ctypes.c_double, i32, vp, i32, vp]
     lib.ldpc_sweep_batch.restype = i32
     lib.ldpc_sweep_batch.argtypes = [vp, ctypes.POINTER(CDecodeConfig), ctypes.POINTER(CChannelConfig), vp, i64, i64, i32, vp, vp]
     lib.ldpc_decode_segments.restype = i32

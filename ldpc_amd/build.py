@@ -42,7 +42,8 @@ UNITS += [("decode_qc_r0.o", "decode_qc_r0.hip", []),
           ("count_errors.o", "count_errors.hip", []),
           ("channel.o", "channel.hip", []),
           ("bitflip.o", "bitflip.hip", []),
-          ("encode_qc.o", "encode_qc.hip", [])]
+          ("encode_qc.o", "encode_qc.hip", []),
+          ("rate_match.o", "rate_match.hip", [])]
 HEADERS = ["bp_common.h", "extra_kernels.h", "sweep_fused.h", "bp_math.h", "spec_common.h", "spec_r1w_plan.h", os.path.join("gen", "codes_gen.h"),
            os.path.join(ROOT, "include", "ldpc_amd.h")]
 

@@ -21,4 +21,10 @@ struct EncDev {
 hipError_t launch_encode_qc(const EncDev &e, const uint8_t *msg, long long frames, uint8_t *cw, int num_cus,
                             hipStream_t stream, bool *supported);
 
+// rate_match.hip: 5G NR bit selection / interleaving and its inverse on LLRs (TS 38.212 5.4.2)
+hipError_t launch_rate_match(const ldpc_rate_match_config &c, const uint8_t *cw, long long cw_stride, long long frames,
+                             uint8_t *out, hipStream_t stream);
+hipError_t launch_rate_recover(const ldpc_rate_match_config &c, const void *llr, int llr_dtype, long long frames,
+                               double filler_llr, int accumulate, void *out, int out_dtype, hipStream_t stream);
+
 }  // namespace ldpc

@@ -437,7 +437,7 @@ extern "C" int32_t ldpc_count_errors(const uint8_t *hard_dev, const uint8_t *ref
     if (frames < 0 || n <= 0) return fail(LDPC_ERR_ARG, "bad frame count or n");
     if (frames == 0) return LDPC_OK;
     if (!hard_dev || !ref_dev || !iters_dev || !converged_dev || !counters_dev) return fail(LDPC_ERR_ARG, "NULL buffer");
-    if (ref_stride != 0 && ref_stride != n) return fail(LDPC_ERR_ARG, "ref_stride must be 0 or n");
+    if (ref_stride != 0 && ref_stride < n) return fail(LDPC_ERR_ARG, "ref_stride must be 0 or at least n");
     hipError_t e = launch_count_errors(hard_dev, ref_dev, ref_stride, iters_dev, converged_dev, frames, n,
                                        reinterpret_cast<unsigned long long *>(counters_dev),
                                        reinterpret_cast<hipStream_t>(stream));
@@ -571,6 +571,48 @@ extern "C" int32_t ldpc_encode_batch(ldpc_encoder *enc, const uint8_t *msg_dev, 
     hipError_t e = launch_encode_qc(enc->dev, msg_dev, frames, cw_dev, enc->num_cus, reinterpret_cast<hipStream_t>(stream), &supported);
     if (e != hipSuccess) return fail(LDPC_ERR_HIP, "encoder launch: %s", hipGetErrorString(e));
     if (!supported) return fail(LDPC_ERR_UNSUPPORTED, "one frame's block columns exceed LDS");
+    return LDPC_OK;
+}
+
+// ------------------------------------------------------------------------------------------ rate matching
+static int check_rm(const ldpc_rate_match_config *c)
+{
+    if (!c) return fail(LDPC_ERR_ARG, "rate matching configuration is NULL");
+    if (c->n_cb < 1 || c->E < 1 || c->offset < 0 || c->n_out < 1) return fail(LDPC_ERR_ARG, "bad rate matching sizes");
+    if (c->k0 < 0 || c->k0 >= c->n_cb) return fail(LDPC_ERR_ARG, "k0 outside the circular buffer");
+    if (c->filler_begin < 0 || c->filler_end < c->filler_begin) return fail(LDPC_ERR_ARG, "bad filler range");
+    const int fa = c->filler_begin < c->n_cb ? c->filler_begin : c->n_cb, fb = c->filler_end < c->n_cb ? c->filler_end : c->n_cb;
+    if (c->n_cb - (fb - fa) < 1) return fail(LDPC_ERR_ARG, "the circular buffer holds fillers only");
+    if (c->Qm < 1 || c->E % c->Qm != 0) return fail(LDPC_ERR_ARG, "E must be a multiple of Qm");
+    return LDPC_OK;
+}
+
+extern "C" int32_t ldpc_rate_match(const ldpc_rate_match_config *cfg, const uint8_t *cw_dev, int64_t cw_stride,
+                                   int64_t frames, uint8_t *out_dev, void *stream)
+{
+    if (int rc = check_rm(cfg)) return rc;
+    if (frames < 0) return fail(LDPC_ERR_ARG, "negative frame count");
+    if (frames == 0) return LDPC_OK;
+    if (!cw_dev || !out_dev) return fail(LDPC_ERR_ARG, "NULL buffer");
+    if (cw_stride < (int64_t)cfg->offset + cfg->n_cb) return fail(LDPC_ERR_ARG, "cw_stride shorter than offset + n_cb");
+    hipError_t e = launch_rate_match(*cfg, cw_dev, cw_stride, frames, out_dev, reinterpret_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(LDPC_ERR_HIP, "rate_match launch: %s", hipGetErrorString(e));
+    return LDPC_OK;
+}
+
+extern "C" int32_t ldpc_rate_recover(const ldpc_rate_match_config *cfg, const void *llr_dev, int32_t llr_dtype,
+                                     int64_t frames, double filler_llr, int32_t accumulate, void *out_dev,
+                                     int32_t out_dtype, void *stream)
+{
+    if (int rc = check_rm(cfg)) return rc;
+    if (frames < 0) return fail(LDPC_ERR_ARG, "negative frame count");
+    if ((llr_dtype != LDPC_F32 && llr_dtype != LDPC_F64) || (out_dtype != LDPC_F32 && out_dtype != LDPC_F64))
+        return fail(LDPC_ERR_ARG, "dtype must be LDPC_F32 or LDPC_F64");
+    if (frames == 0) return LDPC_OK;
+    if (!llr_dev || !out_dev) return fail(LDPC_ERR_ARG, "NULL buffer");
+    hipError_t e = launch_rate_recover(*cfg, llr_dev, llr_dtype, frames, filler_llr, accumulate != 0, out_dev, out_dtype,
+                                       reinterpret_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(LDPC_ERR_HIP, "rate_recover launch: %s", hipGetErrorString(e));
     return LDPC_OK;
 }
 
