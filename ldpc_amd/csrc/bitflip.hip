@@ -74,13 +74,13 @@ hipError_t launch_bitflip(const CsrDev &code, int max_iters, int num_active_chec
     hipError_t e;
     if (io.llr_dtype == LDPC_F64) {
         auto k = bitflip_kernel<double>;
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        e = kernel_setup(reinterpret_cast<const void *>(k), nt, lds, nullptr);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(nt), lds, io.stream, code, max_iters, mact,
                            reinterpret_cast<const double *>(io.llr), io.frames, io.hard, io.iters, io.converged);
     } else {
         auto k = bitflip_kernel<float>;
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        e = kernel_setup(reinterpret_cast<const void *>(k), nt, lds, nullptr);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(nt), lds, io.stream, code, max_iters, mact,
                            reinterpret_cast<const float *>(io.llr), io.frames, io.hard, io.iters, io.converged);

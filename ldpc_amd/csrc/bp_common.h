@@ -3,6 +3,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <map>
+#include <mutex>
+#include <tuple>
+
 #include "ldpc_amd.h"
 
 namespace ldpc {
@@ -88,6 +92,32 @@ inline hipError_t scratch_reserve(Scratch &ws, size_t per_wg, long long want_gri
         if (e != hipSuccess) return e;
         ws.bytes = need;
     }
+    return hipSuccess;
+}
+
+// One-time set-up of a kernel on the current device: raise its dynamic LDS limit to `lds` bytes
+// and (per_cu != NULL) ask the runtime how many workgroups of `threads` threads a compute unit
+// holds.  Both answers are fixed for a (kernel, device, threads, lds) combination, so they are
+// cached: every launch after the first costs one map lookup instead of two runtime calls.
+inline hipError_t kernel_setup(const void *kernel, int threads, size_t lds, int *per_cu)
+{
+    static std::mutex mu;
+    static std::map<std::tuple<const void *, int, int, size_t>, int> cache;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const auto key = std::make_tuple(kernel, dev, threads, lds);
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find(key);
+    if (it == cache.end()) {
+        e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        int nb = 0;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, threads, lds);
+        if (e != hipSuccess) return e;
+        it = cache.emplace(key, nb).first;
+    }
+    if (per_cu) *per_cu = it->second;
     return hipSuccess;
 }
 

@@ -230,8 +230,7 @@ static hipError_t launch_csr_t(const CsrDev &code, const ldpc_decode_config &cfg
     }
     Cfg<T> g = make_cfg<T>(cfg);
     auto go = [&](auto k, const char *n64, const char *n32) -> hipError_t {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = kernel_setup(reinterpret_cast<const void *>(k), nt, lds, nullptr);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(nt), lds, io.stream, code, g,
                            reinterpret_cast<const TL *>(io.llr), io.frames, io.hard, io.iters,

@@ -643,20 +643,14 @@ static hipError_t launch_lnms(const ldpc_decode_config &cfg, const Launch &io, i
         static_lds = (int)attr.sharedSizeBytes;
     }
     if (static_lds != 0) return hipErrorInvalidConfiguration;
-    hipError_t e = hipSuccess;
-    static int per_cu = 0;  // resident workgroups per compute unit, as the runtime computes it
-    if (per_cu == 0) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, LY::LDS_BYTES);
-        if (e != hipSuccess) return e;
-        int nb = 0;
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(k), LY::THREADS, LY::LDS_BYTES);
-        if (e != hipSuccess) return e;
-        per_cu = nb < 1 ? 1 : nb;
-        if (getenv("LDPC_DEBUG_OCCUPANCY"))
-            fprintf(stderr, "lnms_kernel<%s,%d-byte>: %d frames per workgroup, %d block rows in registers, "
-                    "%d workgroups of %d threads per CU, %d B LDS each\n",
-                    C::name, (int)sizeof(T), F, CF::RL, per_cu, LY::THREADS, LY::LDS_BYTES);
-    }
+    int per_cu = 0;  // resident workgroups per compute unit, as the runtime computes it
+    hipError_t e = kernel_setup(reinterpret_cast<const void *>(k), LY::THREADS, LY::LDS_BYTES, &per_cu);
+    if (e != hipSuccess) return e;
+    if (per_cu < 1) per_cu = 1;
+    if (getenv("LDPC_DEBUG_OCCUPANCY"))
+        fprintf(stderr, "lnms_kernel<%s,%d-byte>: %d frames per workgroup, %d block rows in registers, "
+                "%d workgroups of %d threads per CU, %d B LDS each\n",
+                C::name, (int)sizeof(T), F, CF::RL, per_cu, LY::THREADS, LY::LDS_BYTES);
     const long long groups = (io.frames + F - 1) / F;
     const long long full = (long long)num_cus * (long long)per_cu * 2;
     long long grid = full;

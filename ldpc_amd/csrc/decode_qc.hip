@@ -446,8 +446,7 @@ static hipError_t launch_qc_t(const QcDev &q, const ldpc_decode_config &cfg, con
     if (grid > groups) grid = groups;
     if (grid < 1) grid = 1;
     auto k = decode_qc_kernel<RULE, T, TL, DC, DV>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = kernel_setup(reinterpret_cast<const void *>(k), sh.threads, lds, nullptr);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(sh.threads), lds, io.stream, q, make_cfg<T>(cfg), F, sh.W,
                        reinterpret_cast<const TL *>(io.llr), io.frames, io.hard, io.iters,

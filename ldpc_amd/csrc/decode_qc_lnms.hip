@@ -229,11 +229,8 @@ static hipError_t launch_qc_lnms_t(const QcDev &code, const ldpc_decode_config &
     g.float_syndrome0 = 0; g.num_active_checks = -1; g.num_refresh_vars = -1;
     g.scale = (T)cfg.scale; g.clip_tanh_arg = (T)0; g.clip_prod = (T)0; g.clip_post = (T)0; g.offset = (T)0;
     auto launch = [&](auto k) -> hipError_t {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
         int per_cu = 0;
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k), threads, lds);
+        hipError_t e = kernel_setup(reinterpret_cast<const void *>(k), threads, lds, &per_cu);
         if (e != hipSuccess) return e;
         if (per_cu < 1) per_cu = 1;
         const long long groups = (io.frames + F - 1) / F;

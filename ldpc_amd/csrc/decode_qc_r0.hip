@@ -340,8 +340,7 @@ static hipError_t launch_r0_t(const QcDev &q, const ldpc_decode_config &cfg, con
     g.float_syndrome0 = cfg.float_syndrome0; g.num_active_checks = -1; g.num_refresh_vars = -1;
     g.scale = (T)cfg.scale; g.clip_tanh_arg = (T)0; g.clip_prod = (T)0; g.clip_post = (T)0; g.offset = (T)0;
     auto k = decode_qc_r0_kernel<T, TL, DC, DV>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = kernel_setup(reinterpret_cast<const void *>(k), sh.threads, lds, nullptr);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(sh.threads), lds, io.stream, q, g, F, sh.W,
                        reinterpret_cast<const TL *>(io.llr), io.frames, io.hard, io.iters,

@@ -442,17 +442,10 @@ static hipError_t launch_spec_r0(const ldpc_decode_config &cfg, const Launch &io
     g.float_syndrome0 = cfg.float_syndrome0; g.num_active_checks = -1; g.num_refresh_vars = -1;
     g.scale = (T)cfg.scale; g.clip_tanh_arg = (T)0; g.clip_prod = (T)0; g.clip_post = (T)0; g.offset = (T)0;
     auto k = spec_r0_kernel<C, T, TL, F, kFused>;
-    // attributes and occupancy of a kernel do not change: looked up once per instantiation
-    static int per_cu = 0;
-    if (per_cu == 0) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LY::LDS_BYTES);
-        if (e != hipSuccess) return e;
-        int nb = 0;
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(k), LY::THREADS, LY::LDS_BYTES);
-        if (e != hipSuccess) return e;
-        per_cu = nb < 1 ? 1 : nb;
-    }
+    int per_cu = 0;
+    hipError_t e = kernel_setup(reinterpret_cast<const void *>(k), LY::THREADS, LY::LDS_BYTES, &per_cu);
+    if (e != hipSuccess) return e;
+    if (per_cu < 1) per_cu = 1;
     const long long groups = (io.frames + F - 1) / F;
     long long grid = (long long)num_cus * (long long)per_cu * 2;
     if (grid > groups) grid = groups;
@@ -482,13 +475,8 @@ static hipError_t launch_spec_r1(const ldpc_decode_config &cfg, const Launch &io
     if (grid > groups) grid = groups;
     if (grid < 1) grid = 1;
     auto k = spec_r1_kernel<C, T, TL, F, OMS, kFused>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LY::LDS_BYTES);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    hipError_t e = kernel_setup(reinterpret_cast<const void *>(k), 64, LY::LDS_BYTES, nullptr);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(64), LY::LDS_BYTES, io.stream, g,
                        reinterpret_cast<const TL *>(io.llr), io.frames, io.hard, io.iters, io.converged,
                        reinterpret_cast<T *>(io.posterior), sp ? *sp : SweepDev{});

@@ -619,11 +619,8 @@ static hipError_t launch_r1w(const ldpc_decode_config &cfg, const Launch &io, in
     if constexpr (F > 1) {  // early exit with several slots: every slot runs its own queue of frames
         if (cfg.early_exit && cfg.max_iters >= 1) k = spec_r1w_slots_kernel<C, T, TL, F, W, kOms>;
     }
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, LY::LDS_BYTES);
-    if (e != hipSuccess) return e;
     int per_cu = 0;
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k), 64 * W * G, LY::LDS_BYTES);
+    hipError_t e = kernel_setup(reinterpret_cast<const void *>(k), 64 * W * G, LY::LDS_BYTES, &per_cu);
     if (e != hipSuccess) return e;
     if (per_cu < 1) per_cu = 1;
     const long long groups = (io.frames + F - 1) / F;
@@ -684,11 +681,8 @@ static hipError_t launch_r0w(const ldpc_decode_config &cfg, const Launch &io, in
     g.float_syndrome0 = cfg.float_syndrome0; g.num_active_checks = -1; g.num_refresh_vars = -1;
     g.scale = (T)cfg.scale; g.clip_tanh_arg = (T)0; g.clip_prod = (T)0; g.clip_post = (T)0; g.offset = (T)0;
     auto k = spec_r0w_kernel<C, T, TL, F, W>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, LY::LDS_BYTES);
-    if (e != hipSuccess) return e;
     int per_cu = 0;
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k), 64 * W * G, LY::LDS_BYTES);
+    hipError_t e = kernel_setup(reinterpret_cast<const void *>(k), 64 * W * G, LY::LDS_BYTES, &per_cu);
     if (e != hipSuccess) return e;
     if (per_cu < 1) per_cu = 1;
     const long long groups = (io.frames + F - 1) / F;

@@ -190,11 +190,8 @@ static hipError_t launch_spa(const ldpc_decode_config &cfg, const Launch &io, in
     g.scale = (T)cfg.scale; g.clip_tanh_arg = (T)cfg.clip_tanh_arg; g.clip_prod = (T)cfg.clip_prod;
     g.clip_post = (T)cfg.clip_post; g.offset = (T)cfg.offset;
     auto k = spec_spa_kernel<RULE, C, T, TL, F>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, LY::LDS_BYTES);
-    if (e != hipSuccess) return e;
     int per_cu = 0;
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k), 64, LY::LDS_BYTES);
+    hipError_t e = kernel_setup(reinterpret_cast<const void *>(k), 64, LY::LDS_BYTES, &per_cu);
     if (e != hipSuccess) return e;
     if (per_cu < 8) { *supported = false; return hipSuccess; }
     const long long groups = (io.frames + F - 1) / F;

@@ -467,11 +467,8 @@ static hipError_t launch_spaw(const ldpc_decode_config &cfg, const Launch &io, i
     if constexpr (F > 1) {  // early exit with several slots: every slot runs its own queue of frames
         if (cfg.early_exit && cfg.max_iters >= 1) k = spec_spaw_slots_kernel<RULE, C, T, TL, F, W>;
     }
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, LY::LDS_BYTES);
-    if (e != hipSuccess) return e;
     int per_cu = 0;
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k), 64 * W * G, LY::LDS_BYTES);
+    hipError_t e = kernel_setup(reinterpret_cast<const void *>(k), 64 * W * G, LY::LDS_BYTES, &per_cu);
     if (e != hipSuccess) return e;
     if (per_cu < 1) per_cu = 1;
     const long long groups = (io.frames + F - 1) / F;

@@ -74,13 +74,8 @@ hipError_t launch_encode_qc(const EncDev &e, const uint8_t *msg, long long frame
     if (lds > 160 * 1024) return hipSuccess;
     *supported = true;
     const int threads = ((F * e.Z + 63) / 64) * 64;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(encode_qc_kernel),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (err != hipSuccess) return err;
-        attr_set = true;
-    }
+    hipError_t err = kernel_setup(reinterpret_cast<const void *>(encode_qc_kernel), threads, lds, nullptr);
+    if (err != hipSuccess) return err;
     const long long groups = (frames + F - 1) / F;
     long long per_cu = (long long)((160 * 1024) / (lds ? lds : 1));
     if (per_cu > 2048 / threads) per_cu = 2048 / threads;

@@ -52,6 +52,9 @@ struct ldpc_code {
     // scratch of the kernels that keep frame state in global memory, one buffer per stream a decode
     // was enqueued on: launches on different streams may run at the same time and must not share slices
     std::vector<std::pair<hipStream_t, Scratch>> workspaces;
+    // device staging of ldpc_decode_batch_host (inputs and results of one call); grows, never shrinks
+    char *host_stage = nullptr;
+    size_t host_stage_bytes = 0;
     Scratch &workspace_for(hipStream_t stream)
     {
         for (auto &w : workspaces)
@@ -263,6 +266,7 @@ extern "C" int32_t ldpc_code_destroy(ldpc_code *c)
     if (c->d_qc) (void)hipFree(c->d_qc);
     for (auto &w : c->workspaces)
         if (w.second.ptr) (void)hipFree(w.second.ptr);
+    if (c->host_stage) (void)hipFree(c->host_stage);
     delete c;
     return LDPC_OK;
 }
@@ -406,8 +410,14 @@ extern "C" int32_t ldpc_decode_batch_host(ldpc_code *c, const ldpc_decode_config
     const size_t post_b = posterior ? cells * (compute_dtype == LDPC_F64 ? 8 : 4) : 0;
     auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t total = up(llr_b) + up(cells) + up((size_t)frames * 4) + up((size_t)frames) + up(post_b);
-    char *d = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d), total));
+    if (c->host_stage_bytes < total) {  // the staging area is kept between calls: a frame-at-a-time caller pays it once
+        if (c->host_stage) (void)hipFree(c->host_stage);
+        c->host_stage = nullptr;
+        c->host_stage_bytes = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->host_stage), total));
+        c->host_stage_bytes = total;
+    }
+    char *d = c->host_stage;
     char *d_llr = d, *d_hard = d_llr + up(llr_b), *d_it = d_hard + up(cells),
          *d_cv = d_it + up((size_t)frames * 4), *d_post = d_cv + up((size_t)frames);
     int rc = LDPC_OK;
@@ -424,7 +434,6 @@ extern "C" int32_t ldpc_decode_batch_host(ldpc_code *c, const ldpc_decode_config
             if (e == hipSuccess && posterior) e = hipMemcpy(posterior, d_post, post_b, hipMemcpyDeviceToHost);
         }
     }
-    (void)hipFree(d);
     if (rc != LDPC_OK) return rc;
     if (e != hipSuccess) return fail(LDPC_ERR_HIP, "host decode: %s", hipGetErrorString(e));
     return LDPC_OK;
