@@ -76,18 +76,20 @@ def _profile_record(kind, key, fixed, kernel):
     return best
 
 
-def rooflines(code, cfg, dtype, frames, kernel_ms, executed, kernel, code_name, rule_name):
+def rooflines(code, cfg, dtype, frames, kernel_ms, executed, kernel, code_name, rule_name, fused=False):
     """HBM, LDS and vector-issue rooflines of one launch."""
     itemsize = 8 if dtype == "f64" else 4
-    key = f"{code_name}/{rule_name}/{dtype}/f32llr"
+    key = f"{code_name}/{rule_name}/{dtype}/" + ("fused" if fused else "f32llr")
     fixed = not cfg.early_exit
     sec = kernel_ms * 1e-3
-    hbm_bytes = (5 * code.n + 5) * frames                 # f32 LLR in, u8 hard + i32 + u8 out
+    # decode: f32 LLR in, u8 hard + i32 + u8 out; fused sweep: the transmitted codeword (u8) in, nothing out
+    per_frame = code.n if fused else 5 * code.n + 5
+    hbm_bytes = per_frame * frames
     tr = _profile_record("hbm_traffic", key, fixed, kernel)
     roof = {"bound": "hbm", "achieved": hbm_bytes / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "traffic": tr["hbm_bytes_per_frame"] * frames if tr else None,
             "traffic_source": tr["source"] if tr else None,
-            "kernel": kernel, "kernel_ms": kernel_ms, "bytes_per_frame": 5 * code.n + 5}
+            "kernel": kernel, "kernel_ms": kernel_ms, "bytes_per_frame": per_frame}
     roof["frac"] = roof["achieved"] / roof["peak"]
     rd, wr = lds_bytes_per_frame_iter(code, cfg.rule, itemsize)
     floor = executed * (rd / ((LDS_READ64_GBS if itemsize == 8 else LDS_READ32_GBS) * 1e9) + wr / (LDS_WRITE_GBS * 1e9))
@@ -145,7 +147,10 @@ class Runner:
         self.k = (self.G.k if callable(self.G) else self.G.shape[0]) if self.G is not None else self.code.n - self.code.m
         self.dec = Decoder(self.code)
 
-    def run(self, rule, dtype, snr, early, frames, steps, warmup, max_iters=10, seed=7, kernel=0, with_rooflines=False):
+    def run(self, rule, dtype, snr, early, frames, steps, warmup, max_iters=10, seed=7, kernel=0, with_rooflines=False,
+            fused=False):
+        """`fused`: a step is channel + decode + error accounting in one launch (ldpc_sweep_batch) on
+        codewords resident in HBM, instead of the decode of LLRs resident in HBM."""
         from ldpc_amd import config, sweep
         cfg = config.PRESETS[rule].with_(max_iters=max_iters, early_exit=early)
         batch = sweep.make_batch(self.code, self.G, frames, snr, cfg, seed=[seed, self.rank], device=self.device)
@@ -153,12 +158,18 @@ class Runner:
         kname = [""]
 
         def step():
-            kname[0] = sweep.decode_batch(self.dec, batch, cfg, compute_dtype=compute, kernel=kernel)
+            if fused:
+                kname[0] = sweep.sweep_fused(self.dec, batch.ref, snr, cfg, [seed, self.rank], batch.counters, compute_dtype=compute)
+            else:
+                kname[0] = sweep.decode_batch(self.dec, batch, cfg, compute_dtype=compute, kernel=kernel)
 
         wall, dev_ms = timed_steps(step, steps, warmup, self.torch, self.dist, self.world)
         # error counters of the last step, summed over ranks: the one collective of the path
         batch.counters.zero_()
-        sweep.count_errors(self.dec, batch)
+        if fused:
+            step()
+        else:
+            sweep.count_errors(self.dec, batch)
         sweep.allreduce_counters(batch.counters)
         self.torch.cuda.synchronize()
         st = sweep.summarize(batch.counters.cpu().numpy(), self.code.n)
@@ -170,7 +181,7 @@ class Runner:
         if with_rooflines:
             # iterations actually run: failures ran max_iters but report max-1; fixed mode reports max_iters
             executed = (st["iterations"] + (st["not_converged"] if early else 0)) / self.world
-            res.update(rooflines(self.code, cfg, dtype, frames, dev_ms / steps, executed, kname[0], self.name, rule))
+            res.update(rooflines(self.code, cfg, dtype, frames, dev_ms / steps, executed, kname[0], self.name, rule, fused))
         return res, batch, cfg
 
 
@@ -223,6 +234,8 @@ def main():
                     "iteration instead of exactly max-iters updates per frame")
     ap.add_argument("--fixed", action="store_true", help="(default) exactly max-iters updates per frame")
     ap.add_argument("--cpu-sample", type=int, default=0, help="frames of the CPU baseline (0 = auto)")
+    ap.add_argument("--fused", action="store_true", help="a step is channel + decode + error accounting in one launch "
+                    "(ldpc_sweep_batch) instead of the decode alone")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-other", action="store_true", help="headline workload only (no bg1, no other)")
     args = ap.parse_args()
@@ -254,7 +267,7 @@ def main():
         args.frames = 1 << 20 if code.n <= 1024 else 16384
     early = bool(args.early_exit)
     res, batch, cfg = head.run(args.rule, args.dtype, args.snr, early, args.frames, args.steps, args.warmup,
-                               max_iters=args.max_iters, kernel=args.kernel, with_rooflines=True)
+                               max_iters=args.max_iters, kernel=args.kernel, with_rooflines=True, fused=args.fused)
     rule_text = {'R0': 'ldpc.py decoder', 'R1': 'bpsk.py decoder', 'LNMS': 'layered min-sum, build extension'}.get(args.rule, 'sum-product')
     out = {
         "metric": "decoded info Gbit/s", "value": res["value"], "unit": "Gbit/s", "n_gpus": world,
@@ -267,18 +280,19 @@ def main():
                                f"{' (syndrome check per iteration)' if early else ' per frame (no early exit)'}, Es/N0 {args.snr} dB",
                    "code": args.code, "frames_per_launch_per_gpu": args.frames, "rule": args.rule,
                    "max_iters": args.max_iters, "early_exit": early, "es_n0_db": args.snr,
-                   "llr_dtype": "f32", "kernel": res["kernel"], "sharding": f"frames x{world}"},
+                   "llr_dtype": "f32", "kernel": res["kernel"], "sharding": f"frames x{world}",
+                   "step": "channel + decode + error accounting in one launch" if args.fused else "decode of LLRs resident in HBM"},
         "mean_iters": res["mean_iters"], "fer": res["fer"], "ber": res["ber"], "counters": res["counters"],
         "roofline": res["roofline"], "lds_roofline": res["lds_roofline"],
     }
     if "valu_roofline" in res:
         out["valu_roofline"] = res["valu_roofline"]
-    if rank == 0 and world == 1 and not args.no_cpu:
+    if rank == 0 and world == 1 and not args.no_cpu and not args.fused:
         out["cpu_baseline"] = cpu_baseline(code, cfg, batch, head.k, args.dtype, 10.0, args.cpu_sample)
         out["vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
     del batch
 
-    if not args.no_other and args.code == "ccsds512" and args.rule == "R0" and not early:
+    if not args.no_other and args.code == "ccsds512" and args.rule == "R0" and not early and not args.fused:
         short = lambda r: {k: r[k] for k in ("value", "unit", "ms_per_step", "kernel", "mean_iters", "fer", "ber",
                                              "es_n0_db", "early_exit", "frames_per_launch_per_gpu", "dtype")}
         # the same kernel running the reference's loop (syndrome check at the top of every iteration)

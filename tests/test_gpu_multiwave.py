@@ -56,8 +56,9 @@ def test_ragged_batches_match_c_oracle(name, rule, kernel, early, c_oracle):
             assert np.array_equal(res.hard, eh) and np.array_equal(res.posterior, ep)
         else:
             # device transcendentals against libm: a frame on the edge of converging may take a step more
+            # (against numpy, which the reference uses, no frame in 1536 differed: tests/test_gpu_precision.py)
             same = (res.converged == ec) & (res.iters == ei)
-            assert same.mean() >= 0.95
+            assert (~same).sum() <= (1 if B > 100 else 0), int((~same).sum())
             assert np.array_equal(res.hard[same & ec], eh[same & ec])
             scale = np.maximum(np.abs(ep[same]), 1.0)
             assert float(np.max(np.abs(res.posterior[same] - ep[same]) / scale, initial=0.0)) <= 1e-4
@@ -110,7 +111,7 @@ def test_slot_queues_many_frames_per_slot(c_oracle):
     res = decoder_for("wifi648").decode(L, cfg, compute_dtype=np.float64, want_posterior=True)
     assert res.kernel == "spec_spaw_f64"
     same = (res.converged == ec) & (res.iters == ei)
-    assert same.mean() >= 0.99
+    assert (~same).sum() <= 6, int((~same).sum())   # one frame in a thousand against libm's transcendentals
     assert np.array_equal(res.hard[same & ec], eh[same & ec])
     scale = np.maximum(np.abs(ep[same]), 1.0)
     assert float(np.max(np.abs(res.posterior[same] - ep[same]) / scale)) <= 1e-4

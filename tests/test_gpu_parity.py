@@ -86,17 +86,25 @@ def test_f32_matches_reference(path, kernel):
         # converge wander for the whole iteration budget and float32 rounding is amplified along
         # the way, so only their flag and iteration count are comparable.
         assert np.array_equal(res.hard[conv], hard[conv])
-        quick = conv & (iters <= 6)   # rounding differences grow with every iteration
+        # posteriors: rounding differences grow with every iteration.  Measured over 10^5 frames per
+        # rule and code (tests/test_gpu_precision.py): <= 1e-5 relative up to 6 iterations, <= 3e-4 up to
+        # 13; the 1e-4 bar holds for quick frames, slower ones get the measured envelope
+        quick = conv & (iters <= 6)
         assert _rel_err(res.posterior[quick].astype(np.float64), post[quick]) <= 1e-4
-        assert _rel_err(res.posterior[conv].astype(np.float64), post[conv]) <= 5e-2
+        mid = conv & (iters <= 13)
+        assert _rel_err(res.posterior[mid].astype(np.float64), post[mid]) <= 1e-3
     else:
         # float32 saturates the tanh product one ulp below 1 (|message| <= 17.3 instead of 21.4 /
-        # 19.1), so sum-product trajectories are close, not identical: converged frames must
-        # decode to the same word; iteration counts may differ by a step
+        # 19.1), so sum-product posteriors are not comparable; decisions are.  Measured over 10^5
+        # frames (tests/test_gpu_precision.py): the convergence flag differs on < 0.01 % of frames
+        # under the tanh rules and 0.23 % under the phi rule, the iteration count on < 0.01 % / 0.5 %,
+        # and two arithmetic types never decode a frame to different words.  A fixture holds 6-32
+        # frames: at most one of them (two under the phi rule) may differ in flag or count.
+        limit = 2 if cfg.rule == 4 else 1
         same = res.converged & conv
-        assert same.sum() >= 0.9 * conv.sum()
+        assert int((res.converged != conv).sum()) <= limit
+        assert int((res.iters[same] != iters[same]).sum()) <= limit
         assert np.array_equal(res.hard[same], hard[same])
-        assert np.abs(res.iters[same] - iters[same]).max(initial=0) <= 2
 
 
 @pytest.mark.parametrize("rule", ["R0", "R1"])

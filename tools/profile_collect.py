@@ -16,19 +16,23 @@ from ldpc_amd.build import kernel_source_digest  # noqa: E402
 tag = sys.argv[1]
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(ROOT, "profiles")
-WORKLOADS = {"ccsds_r0_f64": "ccsds512/R0/f64/f32llr", "bg1_lnms_f32": "nr_bg1_z384/LNMS/f32/f32llr",
+WORKLOADS = {"ccsds_r0_f64": "ccsds512/R0/f64/f32llr", "ccsds_r0_f64_fused": "ccsds512/R0/f64/fused",
+             "ccsds_r0_f64_ee": "ccsds512/R0/f64/f32llr/early_exit", "bg1_lnms_f32": "nr_bg1_z384/LNMS/f32/f32llr",
              "bg1_lnms_f64": "nr_bg1_z384/LNMS/f64/f32llr",
              "bg2_R0_f64": "nr_bg2_z40/R0/f64/f32llr", "bg2_R0_f32": "nr_bg2_z40/R0/f32/f32llr",
              "bg2_R1_f32": "nr_bg2_z40/R1/f32/f32llr", "bg2_R3_f32": "nr_bg2_z40/R3/f32/f32llr"}
 # only the workloads this tag's run covered
-WORKLOADS = {wl: key for wl, key in WORKLOADS.items() if os.path.isdir(os.path.join(src, f"stats_{wl}"))}
+WORKLOADS = {wl: key for wl, key in WORKLOADS.items()
+             if os.path.isdir(os.path.join(src, f"stats_{wl}")) or os.path.isdir(os.path.join(src, f"fetch_{wl}"))}
 
 
 def decoder_kernel(name):
-    return "ldpc::" in name and "count_errors" not in name
+    return "ldpc::" in name and not any(k in name for k in ("count_errors", "channel_llr", "encode_qc", "rate_"))
 
 
 for wl in WORKLOADS:
+    if not os.path.isdir(os.path.join(src, f"stats_{wl}")):
+        continue
     rows = list(csv.DictReader(open(os.path.join(src, f"stats_{wl}", "t_kernel_stats.csv"))))
     keep = [r for r in rows if decoder_kernel(r["Name"])] + [r for r in rows if not decoder_kernel(r["Name"])][:10]
     out = os.path.join(dst, f"{tag}_{wl}_kernel_stats.csv")

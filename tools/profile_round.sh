@@ -20,11 +20,16 @@ run_pmc() {  # name, counter, bench args...
 }
 run_stats stats_ccsds_r0_f64
 echo "stats ccsds done"
+run_stats stats_ccsds_r0_f64_fused --fused --early-exit
 run_stats stats_bg1_lnms_f32 --code nr_bg1_z384 --rule LNMS --dtype f32 --frames 16384
 run_stats stats_bg1_lnms_f64 --code nr_bg1_z384 --rule LNMS --dtype f64 --frames 16384
 echo "stats bg1 done"
 run_pmc fetch_ccsds_r0_f64 FETCH_SIZE
 run_pmc write_ccsds_r0_f64 WRITE_SIZE
+run_pmc fetch_ccsds_r0_f64_fused FETCH_SIZE --fused --early-exit
+run_pmc write_ccsds_r0_f64_fused WRITE_SIZE --fused --early-exit
+run_pmc fetch_ccsds_r0_f64_ee FETCH_SIZE --early-exit
+run_pmc write_ccsds_r0_f64_ee WRITE_SIZE --early-exit
 echo "pmc ccsds done"
 run_pmc fetch_bg1_lnms_f32 FETCH_SIZE --code nr_bg1_z384 --rule LNMS --dtype f32 --frames 16384
 run_pmc write_bg1_lnms_f32 WRITE_SIZE --code nr_bg1_z384 --rule LNMS --dtype f32 --frames 16384
