@@ -131,7 +131,7 @@ __device__ __forceinline__ void r0_var(const R0Ctx &x, T scale, const_u32 info, 
         pair[k] = (w & 0x8000u) != 0;
         zz[k] = rot_sub(x.z, s, x.Z);
         const typename Num<T>::Pair c = cs[br * x.FZ + x.fz0 + zz[k]];
-        r[k] = Num<T>::flip_sign(ao == t_abs(c.x) ? c.y : c.x, so);  // candidates carry the parity
+        r[k] = ao == t_abs(c.x) ? c.y : c.x;  // candidates carry the parity; the variable's own sign goes on the sum
     }
 #pragma unroll
     for (int k = 0; k + 1 < D; ++k) {
@@ -145,7 +145,7 @@ __device__ __forceinline__ void r0_var(const R0Ctx &x, T scale, const_u32 info, 
     T s = (T)0;
 #pragma unroll
     for (int k = 0; k < D; ++k) s += r[k];
-    post[vi] = scale * (s + L[vi]);
+    post[vi] = scale * (Num<T>::flip_sign(s, so) + L[vi]);
 }
 
 #define R0_CASE_ROW(N)                                                                              \

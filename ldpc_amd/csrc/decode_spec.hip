@@ -203,8 +203,11 @@ spec_r0_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *
                         constexpr int br = C::col_row[k0 + k], s = C::col_shift[k0 + k];
                         off[k] = rot_bwd<Z, SP, s>(zp);
                         const Pair c = *reinterpret_cast<const Pair *>(cs_b + br * Z * SP + off[k]);
-                        // both candidates already carry the check's sign parity
-                        r[k] = SNum<T>::flip_sign(ao == t_abs(c.x) ? c.y : c.x, so);
+                        // both candidates already carry the check's sign parity; the variable's own sign
+                        // is common to all its messages and is applied once, to their sum (negating
+                        // every term of a sum negates the sum exactly; a sum of +0.0 that would have
+                        // been -0.0 vanishes in the addition of the channel value below)
+                        r[k] = ao == t_abs(c.x) ? c.y : c.x;
                     });
                     static_for<0, (D > 0 ? D - 1 : 0)>([&](auto k) {
                         if constexpr (C::col_pair[k0 + k] != 0) {  // lower check index first
@@ -216,7 +219,7 @@ spec_r0_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *
                     });
                     T s = (T)0;  // ldpc.py:173,188
                     static_for<0, D>([&](auto k) { s += r[k]; });
-                    own[bc] = g.scale * (s + L[bc]);  // ldpc.py:196
+                    own[bc] = g.scale * (SNum<T>::flip_sign(s, so) + L[bc]);  // ldpc.py:196
                     *reinterpret_cast<T *>(post_b + bc * Z * ST + zb) = own[bc];
                 });
             }

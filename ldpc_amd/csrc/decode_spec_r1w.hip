@@ -545,7 +545,7 @@ spec_r0w_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t 
                                     constexpr int br = C::col_row[k0 + k], s = C::col_shift[k0 + k];
                                     off[k] = rot_bwd<Z, SP, s>(zp);
                                     const Pair c = *reinterpret_cast<const Pair *>(cs_b + br * Z * SP + off[k]);
-                                    r[k] = SNum<T>::flip_sign(ao == t_abs(c.x) ? c.y : c.x, so);
+                                    r[k] = ao == t_abs(c.x) ? c.y : c.x;  // the variable's own sign is applied to the sum
                                 });
                                 static_for<0, (D > 0 ? D - 1 : 0)>([&](auto k) {
                                     if constexpr (C::col_pair[k0 + k] != 0) {  // lower check index first
@@ -557,7 +557,7 @@ spec_r0w_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t 
                                 });
                                 T sum = (T)0;
                                 static_for<0, D>([&](auto k) { sum += r[k]; });
-                                own[j] = g.scale * (sum + L[j]);  // ldpc.py:196
+                                own[j] = g.scale * (SNum<T>::flip_sign(sum, so) + L[j]);  // ldpc.py:196
                                 *reinterpret_cast<T *>(post_b + bc * Z * ST + zb) = own[j];
                             }
                         });
