@@ -441,7 +441,7 @@ def link_workloads(head, bg2, args, torch, dist, device, world, rank):
     r = nr_rate_match.RateMatch(1, 384, 2 * 8448)
     llr = torch.randn((fr, r.E), device=device, dtype=torch.float32)
     out = torch.empty((fr, r.n_active()), device=device, dtype=torch.float32)
-    w, _ = timed_steps(lambda: r.recover_device(llr, r.n_active(), into=None, out_dtype=torch.float32), 3, 2, torch, dist, world)
+    w, _ = timed_steps(lambda: r.recover_device(llr, r.n_active(), out=out), 3, 2, torch, dist, world)
     res["rate_recover_bg1_rate_half"] = {"gb_s": fr * 4 * (r.E + r.n_active()) * world * 3 / w / 1e9, "frames": fr,
                                          "bytes_per_frame": 4 * (r.E + r.n_active()), "E": r.E, "n_active": r.n_active()}
     del out

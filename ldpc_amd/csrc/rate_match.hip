@@ -54,18 +54,23 @@ static RmIndex make_index(const ldpc_rate_match_config &c)
     return x;
 }
 
+// One thread per transmitted bit / per codeword position; blockIdx.y owns a contiguous run of frames,
+// so the index arithmetic of a position is done once and reused for every frame of the run, a
+// workgroup walks through memory frame by frame, and neighbouring threads touch neighbouring bytes
+// of the same frame.
 __global__ void __launch_bounds__(256)
 rate_match_kernel(RmIndex x, int offset, const uint8_t *__restrict__ cw, long long cw_stride, long long frames,
                   uint8_t *__restrict__ out)
 {
-    const long long total = frames * x.E;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const long long f = i / x.E;
-        const int k = (int)(i - f * x.E);
-        int r = x.rank0 + k % x.M;
-        if (r >= x.M) r -= x.M;
-        out[f * x.E + x.air(k)] = cw[f * cw_stride + offset + x.unrank(r)];
-    }
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= x.E) return;
+    int r = x.rank0 + k % x.M;
+    if (r >= x.M) r -= x.M;
+    const int from = offset + x.unrank(r), to = x.air(k);
+    const long long run = (frames + gridDim.y - 1) / gridDim.y, f0 = blockIdx.y * run;
+    const long long f1 = f0 + run < frames ? f0 + run : frames;
+#pragma unroll 4
+    for (long long f = f0; f < f1; ++f) out[f * x.E + to] = cw[f * cw_stride + from];
 }
 
 template <typename TI, typename TO>
@@ -73,37 +78,48 @@ __global__ void __launch_bounds__(256)
 rate_recover_kernel(RmIndex x, int offset, int n_out, const TI *__restrict__ llr, long long frames, float filler_llr,
                     int accumulate, TO *__restrict__ out)
 {
-    const long long total = frames * n_out;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const long long f = i / n_out;
-        const int pos = (int)(i - f * n_out), d = pos - offset;
+    const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos >= n_out) return;
+    const int d = pos - offset;
+    const bool in_buffer = d >= 0 && d < x.n_cb, filler = in_buffer && d >= x.fa && d < x.fb;
+    int idx = x.E;  // first lap on which this position is sent; E = never
+    if (in_buffer && !filler) {
+        idx = x.rank(d) - x.rank0;
+        if (idx < 0) idx += x.M;
+    }
+    const bool once = idx + x.M >= x.E;  // sent at most once: the usual case
+    const int a0 = idx < x.E ? x.air(idx) : 0;
+    const long long run = (frames + gridDim.y - 1) / gridDim.y, f0 = blockIdx.y * run;
+    const long long f1 = f0 + run < frames ? f0 + run : frames;
+#pragma unroll 4
+    for (long long f = f0; f < f1; ++f) {
         TO v = (TO)0;
-        bool filler = false;
-        if (d >= 0 && d < x.n_cb) {
-            if (d >= x.fa && d < x.fb) {
-                filler = true;
-            } else {
-                int idx = x.rank(d) - x.rank0;
-                if (idx < 0) idx += x.M;
-                const TI *e = llr + f * x.E;
-                for (int k = idx; k < x.E; k += x.M) v += (TO)e[x.air(k)];
-            }
+        const TI *e = llr + f * x.E;
+        if (once) {
+            if (idx < x.E) v = (TO)e[a0];
+        } else {
+            for (int k = idx; k < x.E; k += x.M) v += (TO)e[x.air(k)];
         }
-        if (filler) out[i] = (TO)filler_llr;
-        else out[i] = accumulate ? out[i] + v : v;
+        TO *o = out + f * n_out + pos;
+        if (filler) *o = (TO)filler_llr;
+        else *o = accumulate ? *o + v : v;
     }
 }
 
-static int rm_blocks(long long total)
+static dim3 rm_grid(int width, long long frames)
 {
-    long long b = (total + 255) / 256;
-    return (int)(b > 16384 ? 16384 : (b < 1 ? 1 : b));
+    const unsigned bx = (unsigned)((width + 255) / 256);
+    long long by = 16384 / (bx ? bx : 1);  // about 16 K workgroups in all
+    if (by > frames) by = frames;
+    if (by > 65535) by = 65535;
+    if (by < 1) by = 1;
+    return dim3(bx, (unsigned)by);
 }
 
 hipError_t launch_rate_match(const ldpc_rate_match_config &c, const uint8_t *cw, long long cw_stride, long long frames,
                              uint8_t *out, hipStream_t stream)
 {
-    hipLaunchKernelGGL(rate_match_kernel, dim3(rm_blocks(frames * c.E)), dim3(256), 0, stream, make_index(c), c.offset,
+    hipLaunchKernelGGL(rate_match_kernel, rm_grid(c.E, frames), dim3(256), 0, stream, make_index(c), c.offset,
                        cw, cw_stride, frames, out);
     return hipGetLastError();
 }
@@ -112,7 +128,7 @@ hipError_t launch_rate_recover(const ldpc_rate_match_config &c, const void *llr,
                                double filler_llr, int accumulate, void *out, int out_dtype, hipStream_t stream)
 {
     const RmIndex x = make_index(c);
-    const dim3 grid(rm_blocks(frames * c.n_out)), block(256);
+    const dim3 grid = rm_grid(c.n_out, frames), block(256);
 #define LDPC_RM_GO(TI, TO)                                                                         \
     hipLaunchKernelGGL((rate_recover_kernel<TI, TO>), grid, block, 0, stream, x, c.offset, c.n_out, \
                        reinterpret_cast<const TI *>(llr), frames, (float)filler_llr, accumulate, reinterpret_cast<TO *>(out))

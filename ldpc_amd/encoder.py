@@ -213,7 +213,7 @@ class DeviceEncoder:
         h = getattr(self, "_h", None)
         if h is not None and h.value:
             self._lib.ldpc_encoder_destroy(h)
-            self._h = ctypes.c_void_p()
+            h.value = None   # (module globals may already be gone at interpreter shutdown)
 
 
 def device_encoder(code: CompiledCode, G: Optional[np.ndarray] = None, device: int = 0) -> Optional[DeviceEncoder]:

@@ -202,13 +202,16 @@ class RateMatch:
                                                torch.cuda.current_stream().cuda_stream or None))
         return out
 
-    def recover_device(self, llr, n_out: int, filler_llr: float = 100.0, into=None, out_dtype=None):
+    def recover_device(self, llr, n_out: int, filler_llr: float = 100.0, into=None, out_dtype=None, out=None):
         """llr: torch float [frames, E] -> LLRs of codeword positions [0, n_out); ``into`` = a buffer of
-        an earlier transmission to combine with."""
+        an earlier transmission to combine with, ``out`` = a buffer to overwrite."""
         import torch
         from . import _lib
         llr = llr.contiguous()
-        out = into if into is not None else torch.empty((llr.shape[0], n_out), dtype=out_dtype or llr.dtype, device=llr.device)
+        if into is not None:
+            out = into
+        elif out is None:
+            out = torch.empty((llr.shape[0], n_out), dtype=out_dtype or llr.dtype, device=llr.device)
         assert out.shape == (llr.shape[0], n_out) and out.is_contiguous()
         cfg = self.c_config(n_out)
         dt = lambda t: 1 if t.dtype == torch.float64 else 0
