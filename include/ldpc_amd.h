@@ -69,6 +69,13 @@ extern "C" {
 
 #define LDPC_F32 0
 #define LDPC_F64 1
+/*
+ * compute_dtype only: packed half precision, two frames per lane - a reduced-precision fast mode with
+ * no counterpart in the reference (which computes in float64).  Not bit-exact with anything; meant for
+ * error-rate sweeps, validated statistically against the float32 kernels.  Served for rule R1 on the
+ * small compiled-in codes with float LLRs and posterior_dev = NULL; LDPC_ERR_UNSUPPORTED otherwise.
+ */
+#define LDPC_F16 2
 
 #define LDPC_KERNEL_AUTO 0 /* circulant kernel when the code has QC structure, else edge-list   */
 #define LDPC_KERNEL_CSR 1  /* generic edge-list kernel                                          */

@@ -33,7 +33,8 @@ UNITS += [("decode_spec_spa.o", "decode_spec_spa.hip", []),
           ("decode_spec_r1w_r1.o", "decode_spec_r1w.hip", ["-DLDPC_R1W_RULE=1"]),
           ("decode_spec_r1w_r0.o", "decode_spec_r1w.hip", ["-DLDPC_R1W_RULE=0"]),
           ("decode_spec_r1w_r6.o", "decode_spec_r1w.hip", ["-DLDPC_R1W_RULE=6"]),
-          ("decode_spec.o", "decode_spec.hip", [])]
+          ("decode_spec.o", "decode_spec.hip", []),
+          ("decode_spec_h.o", "decode_spec_h.hip", [])]
 UNITS += [(f"decode_qc_r{k}.o", "decode_qc.hip", [f"-DLDPC_QC_RULE={k}"]) for k in (1, 2, 3, 4, 6)]
 UNITS += [("decode_qc_r0.o", "decode_qc_r0.hip", []),
           ("decode_qc_lnms.o", "decode_qc_lnms.hip", []),
@@ -52,7 +53,7 @@ HEADERS = ["bp_common.h", "extra_kernels.h", "sweep_fused.h", "bp_math.h", "spec
 KERNEL_SOURCES = {"spec_lnms": ["decode_lnms.hip"], "spec_r0w": ["decode_spec_r1w.hip", "spec_r1w_plan.h"],
                   "spec_r1w": ["decode_spec_r1w.hip", "spec_r1w_plan.h"], "spec_spaw": ["decode_spec_spaw.hip", "spec_r1w_plan.h"],
                   "spec_spa": ["decode_spec_spa.hip"], "spec_r0": ["decode_spec.hip"], "spec_r1": ["decode_spec.hip"],
-                  "spec_oms": ["decode_spec.hip"], "spec_omsw": ["decode_spec_r1w.hip", "spec_r1w_plan.h"], "qc_lnms": ["decode_qc_lnms.hip"], "qc_r0": ["decode_qc_r0.hip"],
+                  "spec_oms": ["decode_spec.hip"], "spec_r1_f16x2": ["decode_spec_h.hip"], "spec_omsw": ["decode_spec_r1w.hip", "spec_r1w_plan.h"], "qc_lnms": ["decode_qc_lnms.hip"], "qc_r0": ["decode_qc_r0.hip"],
                   "qc": ["decode_qc.hip"], "csr": ["decode_csr.hip"]}
 
 

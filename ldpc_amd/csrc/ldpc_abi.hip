@@ -301,12 +301,27 @@ static int decode_impl(ldpc_code *c, const ldpc_decode_config *cfg, const void *
     if (!c) return fail(LDPC_ERR_ARG, "code is NULL");
     if (int rc = check_cfg(cfg)) return rc;
     if (frames < 0) return fail(LDPC_ERR_ARG, "negative frame count");
-    if ((llr_dtype != LDPC_F32 && llr_dtype != LDPC_F64) || (compute_dtype != LDPC_F32 && compute_dtype != LDPC_F64))
-        return fail(LDPC_ERR_ARG, "dtype must be LDPC_F32 or LDPC_F64");
+    if ((llr_dtype != LDPC_F32 && llr_dtype != LDPC_F64) ||
+        (compute_dtype != LDPC_F32 && compute_dtype != LDPC_F64 && compute_dtype != LDPC_F16))
+        return fail(LDPC_ERR_ARG, "llr_dtype must be LDPC_F32 or LDPC_F64, compute_dtype LDPC_F32, LDPC_F64 or LDPC_F16");
     if (kernel < LDPC_KERNEL_AUTO || kernel > LDPC_KERNEL_QC) return fail(LDPC_ERR_ARG, "unknown kernel selector %d", kernel);
     if (frames == 0) { g_kernel = "none"; return LDPC_OK; }
     if (!llr_dev || !hard_dev || !iters_dev || !converged_dev) return fail(LDPC_ERR_ARG, "NULL buffer");
     HIP_TRY(hipSetDevice(c->device));
+    if (compute_dtype == LDPC_F16) {  // reduced-precision fast mode: its own kernel, nothing to fall back to
+        const bool plain = cfg->num_active_checks < 0 && cfg->num_refresh_vars < 0 && !(cfg->clip_post > 0.0) && kernel == LDPC_KERNEL_AUTO;
+        bool supported = false;
+        if (plain && c->has_qc && c->spec_id >= 0 && !posterior_dev) {
+            Launch ioh{llr_dev, llr_dtype, (long long)frames, hard_dev, iters_dev, converged_dev, nullptr,
+                       reinterpret_cast<hipStream_t>(stream)};
+            hipError_t e = launch_spec_half(c->spec_id, *cfg, ioh, c->num_cus, &g_kernel, &supported);
+            if (e != hipSuccess) return fail(LDPC_ERR_HIP, "half-precision kernel launch: %s", hipGetErrorString(e));
+        }
+        if (!supported)
+            return fail(LDPC_ERR_UNSUPPORTED, "the half-precision fast mode serves rule R1 on the small compiled-in codes "
+                                              "(float LLRs, no posteriors, no loop-bound quirks, automatic kernel choice)");
+        return LDPC_OK;
+    }
 
     Launch io{llr_dev, llr_dtype, (long long)frames, hard_dev, iters_dev, converged_dev, posterior_dev,
               reinterpret_cast<hipStream_t>(stream)};
@@ -402,8 +417,10 @@ extern "C" int32_t ldpc_decode_batch_host(ldpc_code *c, const ldpc_decode_config
     if (frames < 0) return fail(LDPC_ERR_ARG, "negative frame count");
     if (frames == 0) return ldpc_decode_batch(c, cfg, nullptr, llr_dtype, compute_dtype, kernel, 0, nullptr, nullptr, nullptr, nullptr, nullptr);
     if (!llr || !hard || !iters || !converged) return fail(LDPC_ERR_ARG, "NULL buffer");
-    if ((llr_dtype != LDPC_F32 && llr_dtype != LDPC_F64) || (compute_dtype != LDPC_F32 && compute_dtype != LDPC_F64))
-        return fail(LDPC_ERR_ARG, "dtype must be LDPC_F32 or LDPC_F64");
+    if ((llr_dtype != LDPC_F32 && llr_dtype != LDPC_F64) ||
+        (compute_dtype != LDPC_F32 && compute_dtype != LDPC_F64 && compute_dtype != LDPC_F16))
+        return fail(LDPC_ERR_ARG, "llr_dtype must be LDPC_F32 or LDPC_F64, compute_dtype LDPC_F32, LDPC_F64 or LDPC_F16");
+    if (compute_dtype == LDPC_F16 && posterior) return fail(LDPC_ERR_UNSUPPORTED, "the half-precision fast mode hands back no posteriors");
     HIP_TRY(hipSetDevice(c->device));
     const size_t cells = (size_t)frames * c->n;
     const size_t llr_b = cells * (llr_dtype == LDPC_F64 ? 8 : 4);
@@ -633,6 +650,7 @@ extern "C" int32_t ldpc_sweep_batch(ldpc_code *c, const ldpc_decode_config *cfg,
     if (int rc = check_cfg(cfg)) return rc;
     if (!ch) return fail(LDPC_ERR_ARG, "channel is NULL");
     if (frames < 0) return fail(LDPC_ERR_ARG, "negative frame count");
+    if (compute_dtype == LDPC_F16) return fail(LDPC_ERR_UNSUPPORTED, "no fused sweep in half precision; use the three calls");
     if (compute_dtype != LDPC_F32 && compute_dtype != LDPC_F64) return fail(LDPC_ERR_ARG, "dtype must be LDPC_F32 or LDPC_F64");
     if (!counters_dev) return fail(LDPC_ERR_ARG, "NULL buffer");
     if (ref_dev && ref_stride != 0 && ref_stride != c->n) return fail(LDPC_ERR_ARG, "ref_stride must be 0 or n");

@@ -32,6 +32,8 @@ def _dtype_code(dt) -> int:
     dt = np.dtype(dt)
     if dt == np.float32:
         return _lib.F32
+    if dt == np.float16:   # arithmetic type only: the packed half-precision fast mode (LDPC_F16)
+        return 2
     if dt == np.float64:
         return _lib.F64
     raise TypeError(f"LLRs must be float32 or float64, not {dt}")
@@ -86,7 +88,7 @@ class Decoder:
         hard = np.zeros((B, self.code.n), np.uint8)
         iters = np.zeros(B, np.int32)
         conv = np.zeros(B, np.uint8)
-        post = np.zeros((B, self.code.n), compute_dtype) if want_posterior else None
+        post = np.zeros((B, self.code.n), np.float32 if np.dtype(compute_dtype) == np.float16 else compute_dtype) if want_posterior else None
         ccfg = CDecodeConfig.from_config(cfg)
         _lib.check(self._lib.ldpc_decode_batch_host(
             self._h, ctypes.byref(ccfg), llr.ctypes.data if B else None, _dtype_code(llr.dtype),

@@ -17,7 +17,7 @@ import numpy as np
 
 from .codes import CompiledCode
 from .config import DecodeConfig
-from .decoder import Decoder
+from .decoder import Decoder, _dtype_code
 from ._lib import LDPC_ERR_UNSUPPORTED, LdpcError
 
 COUNTER_NAMES = ("frames", "not_converged", "converged_wrong", "bit_errors", "iterations")
@@ -180,7 +180,7 @@ def decode_mixed(parts, cfg: DecodeConfig, compute_dtype=np.float64, kernel: int
                                 bt.converged.data_ptr(), None, streams[i].cuda_stream)
     ccfg = CDecodeConfig.from_config(cfg)
     _lib.check(lib.ldpc_decode_segments(segs, len(parts), ctypes.byref(ccfg), 0 if llr_dtype == torch.float32 else 1,
-                                        1 if np.dtype(compute_dtype) == np.float64 else 0, kernel))
+                                        _dtype_code(compute_dtype), kernel))
     names = []
     for i, (dec, bt) in enumerate(parts):
         if counters is not None:
@@ -226,7 +226,7 @@ def sweep_fused(dec: Decoder, cw, snr_db: float, cfg: DecodeConfig, seed, counte
     ccfg = CDecodeConfig.from_config(cfg)
     frames, n = cw.shape
     _lib.check(_lib.load().ldpc_sweep_batch(dec._h, ctypes.byref(ccfg), ctypes.byref(ch), cw.data_ptr(), n, frames,
-                                            1 if np.dtype(compute_dtype) == np.float64 else 0, counters.data_ptr(),
+                                            _dtype_code(compute_dtype), counters.data_ptr(),
                                             stream or None))
     return _lib.last_kernel()
 
