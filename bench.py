@@ -154,7 +154,7 @@ class Runner:
         from ldpc_amd import config, sweep
         cfg = config.PRESETS[rule].with_(max_iters=max_iters, early_exit=early)
         batch = sweep.make_batch(self.code, self.G, frames, snr, cfg, seed=[seed, self.rank], device=self.device)
-        compute = np.float64 if dtype == "f64" else np.float32
+        compute = {"f64": np.float64, "f32": np.float32, "f16": np.float16}[dtype]
         kname = [""]
 
         def step():
@@ -364,6 +364,8 @@ def other_workloads(head, args, torch, dist, device, world, rank):
         ("R1_f64_fixed_10", "R1", "f64", 1.0, False),
         ("R1_f32_fixed_10", "R1", "f32", 1.0, False),
         ("R1_f64_es_n0_1dB", "R1", "f64", 1.0, True),
+        ("R1_f16x2_fixed_10", "R1", "f16", 1.0, False),      # packed half precision, two frames per lane: reduced precision
+        ("R1_f16x2_es_n0_1dB", "R1", "f16", 1.0, True),
         ("R3_f32_fixed_10", "R3", "f32", 1.0, False),
     ]:
         run(label, head, rule, dtype, snr, early, frames if rule != "R3" else frames // 4)
