@@ -442,10 +442,11 @@ def link_workloads(head, bg2, args, torch, dist, device, world, rank):
                               "frames": fr, "bytes_per_frame": enc.k + enc.n}
     r = nr_rate_match.RateMatch(1, 384, 2 * 8448)
     llr = torch.randn((fr, r.E), device=device, dtype=torch.float32)
-    out = torch.empty((fr, r.n_active()), device=device, dtype=torch.float32)
-    w, _ = timed_steps(lambda: r.recover_device(llr, r.n_active(), out=out), 3, 2, torch, dist, world)
-    res["rate_recover_bg1_rate_half"] = {"gb_s": fr * 4 * (r.E + r.n_active()) * world * 3 / w / 1e9, "frames": fr,
-                                         "bytes_per_frame": 4 * (r.E + r.n_active()), "E": r.E, "n_active": r.n_active()}
+    n_act = r.n_active()
+    out = torch.empty((fr, n_act), device=device, dtype=torch.float32)
+    w, _ = timed_steps(lambda: r.recover_device(llr, n_act, out=out), 3, 2, torch, dist, world)
+    res["rate_recover_bg1_rate_half"] = {"gb_s": fr * 4 * (r.E + n_act) * world * 3 / w / 1e9, "frames": fr,
+                                         "bytes_per_frame": 4 * (r.E + n_act), "E": r.E, "n_active": n_act}
     del out
     return res
 

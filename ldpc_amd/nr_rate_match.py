@@ -136,8 +136,8 @@ class RateMatch:
     def filler_range(self) -> Tuple[int, int]:   # in buffer positions
         return self.K - self.fillers - self.offset, self.K - self.offset
 
-    def positions(self) -> np.ndarray:
-        """Buffer position of e_k, k = 0 .. E-1 (38.212 section 5.4.2.1, the loop restated)."""
+    def positions_by_walk(self) -> np.ndarray:
+        """Buffer position of e_k, k = 0 .. E-1: the loop of 38.212 section 5.4.2.1 restated literally."""
         fa, fb = self.filler_range
         out = np.empty(self.E, np.int64)
         k = j = 0
@@ -148,6 +148,16 @@ class RateMatch:
                 k += 1
             j += 1
         return out
+
+    def positions(self) -> np.ndarray:
+        """The same in closed form (what the device kernels compute): positions are ranked among the
+        non-filler positions of the buffer, e_k is the one of rank (rank(k0) + k) mod M."""
+        fa, fb = (min(x, self.n_cb) for x in self.filler_range)
+        nf = max(fb - fa, 0)
+        M = self.n_cb - nf
+        rank0 = self.k0 - min(max(self.k0 - fa, 0), nf)
+        r = (rank0 + np.arange(self.E, dtype=np.int64)) % M
+        return np.where(r < fa, r, r + nf)
 
     def air_order(self) -> np.ndarray:
         """Index in the transmitted sequence f of e_k (section 5.4.2.2: f[i + j Qm] = e[i E/Qm + j])."""
