@@ -111,7 +111,7 @@ class RateMatch:
             object.__setattr__(self, "n_cb", N)
         if not 0 < self.n_cb <= N or self.E < 1 or self.E % self.Qm or self.rv not in (0, 1, 2, 3):
             raise ValueError("bad rate matching parameters")
-        if not 0 <= self.fillers < kb_cols * self.Z:
+        if not 0 <= self.fillers <= (kb_cols - 2) * self.Z:   # fillers never reach into the punctured 2 Z prefix
             raise ValueError("bad filler count")
 
     @property
