@@ -225,6 +225,16 @@ int32_t ldpc_channel_llr(const uint8_t *ref_dev, int64_t ref_stride, int64_t fra
                          int32_t llr_dtype, void *stream);
 
 /*
+ * The one collective of the multi-GPU path: sum `count` 64-bit counters (ldpc_count_errors /
+ * ldpc_sweep_batch layout) over the ranks of an RCCL communicator, in place, enqueued on `stream`.
+ * The reference is a single process (its FER loop adds into Python integers, ldpc.py:660-667); with
+ * frames sharded over GPUs each rank counts its own frames and the sums meet here.  rccl_comm is the
+ * caller's ncclComm_t; the library looks RCCL up at run time (the copy already loaded in the
+ * process, else librccl.so.1) and does not link it.  rccl_comm = NULL: single rank, no-op.
+ */
+int32_t ldpc_allreduce_counters(void *rccl_comm, uint64_t *counters_dev, int32_t count, void *stream);
+
+/*
  * ldpc_channel_llr under a Doppler-shifted carrier.  The reference holds no such signal path, only
  * the time-scale factor 1 - v/c of a receiver moving at speed v through a medium of wave speed c
  * (/root/reference/plotDoppler.py:5-6,14-16); the channel is this build's definition: the receiver

@@ -126,7 +126,7 @@ def build(force: bool = False, jobs: int = 8, verbose: bool = True) -> str:
         list(pool.map(run, todo))
     objs = [os.path.join(OBJ, obj) for obj, _, _ in UNITS]
     if force or todo or _stale(LIB, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"{' '.join(cmd)}\n{r.stdout}\n{r.stderr}")

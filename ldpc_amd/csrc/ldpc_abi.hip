@@ -8,6 +8,8 @@
 #include <mutex>
 #include <string>
 #include <utility>
+#include <dlfcn.h>
+
 #include <memory>
 #include <vector>
 
@@ -507,6 +509,43 @@ extern "C" int32_t ldpc_channel_llr_doppler(const uint8_t *ref_dev, int64_t ref_
 {
     return channel_impl(ref_dev, ref_stride, frames, n, sigma2, gain, plus_is_bit, prefix_len, prefix_llr, seed,
                         first_frame, cfo_cycles_per_symbol, phase0_cycles, llr_dev, llr_dtype, stream);
+}
+
+// ------------------------------------------------------------------------------------------ collective
+// RCCL is looked up at the first call, not linked: a process that already holds an RCCL (PyTorch
+// bundles one) must run the collective in THAT copy, the one its communicator belongs to.
+typedef int (*nccl_allreduce_fn)(const void *, void *, size_t, int, int, void *, hipStream_t);
+static nccl_allreduce_fn find_allreduce(std::string *where)
+{
+    static std::mutex mu;
+    static nccl_allreduce_fn fn = nullptr;
+    static std::string found;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!fn) {
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        void *h = nullptr;
+        for (const char *nm : names)  // a copy that is already in the process first
+            if ((h = dlopen(nm, RTLD_NOW | RTLD_NOLOAD))) { found = std::string(nm) + " (already loaded)"; break; }
+        if (!h)
+            for (const char *nm : names)
+                if ((h = dlopen(nm, RTLD_NOW | RTLD_LOCAL))) { found = nm; break; }
+        if (h) fn = reinterpret_cast<nccl_allreduce_fn>(dlsym(h, "ncclAllReduce"));
+    }
+    if (where) *where = found;
+    return fn;
+}
+
+extern "C" int32_t ldpc_allreduce_counters(void *rccl_comm, uint64_t *counters_dev, int32_t count, void *stream)
+{
+    if (!counters_dev || count < 0) return fail(LDPC_ERR_ARG, "NULL buffer or negative count");
+    if (!rccl_comm || count == 0) return LDPC_OK;  // one rank without a communicator: nothing to add
+    std::string where;
+    nccl_allreduce_fn fn = find_allreduce(&where);
+    if (!fn) return fail(LDPC_ERR_UNSUPPORTED, "no RCCL library found (librccl.so.1): %s", dlerror() ? dlerror() : "not on the library path");
+    const int rc = fn(counters_dev, counters_dev, (size_t)count, /*ncclUint64*/ 5, /*ncclSum*/ 0, rccl_comm,
+                      reinterpret_cast<hipStream_t>(stream));
+    if (rc != 0) return fail(LDPC_ERR_HIP, "ncclAllReduce in %s failed with ncclResult_t %d", where.c_str(), rc);
+    return LDPC_OK;
 }
 
 // ------------------------------------------------------------------------------------------ encoder
