@@ -541,7 +541,10 @@ extern "C" int32_t ldpc_allreduce_counters(void *rccl_comm, uint64_t *counters_d
     if (!rccl_comm || count == 0) return LDPC_OK;  // one rank without a communicator: nothing to add
     std::string where;
     nccl_allreduce_fn fn = find_allreduce(&where);
-    if (!fn) return fail(LDPC_ERR_UNSUPPORTED, "no RCCL library found (librccl.so.1): %s", dlerror() ? dlerror() : "not on the library path");
+    if (!fn) {
+        const char *why = dlerror();
+        return fail(LDPC_ERR_UNSUPPORTED, "no RCCL library found (librccl.so.1): %s", why ? why : "not on the library path");
+    }
     const int rc = fn(counters_dev, counters_dev, (size_t)count, /*ncclUint64*/ 5, /*ncclSum*/ 0, rccl_comm,
                       reinterpret_cast<hipStream_t>(stream));
     if (rc != 0) return fail(LDPC_ERR_HIP, "ncclAllReduce in %s failed with ncclResult_t %d", where.c_str(), rc);
