@@ -275,6 +275,15 @@ int32_t ldpc_encoder_create(int32_t Z, int32_t n_cols, int32_t nb, int32_t k_col
                             int32_t device, ldpc_encoder **out);
 void ldpc_encoder_destroy(ldpc_encoder *enc);
 int32_t ldpc_encode_batch(ldpc_encoder *enc, const uint8_t *msg_dev, int64_t frames, uint8_t *cw_dev, void *stream);
+/*
+ * The same with random messages drawn on the device, the counterpart of
+ * `numpy.random.randint(0, 2, k)` per frame in the reference's loop (/root/reference/ldpc.py:649):
+ * message bit i of frame f is bit (i mod 128) of Philox4x32-10 with counter (first_frame + f, i / 128, 1)
+ * and key `seed` - a function of (seed, absolute frame index, bit) only, so a sweep sends the same
+ * messages however it is cut into launches, ranks or GPUs.  msg_out_dev: [frames, k] bytes, or NULL.
+ */
+int32_t ldpc_encode_random(ldpc_encoder *enc, uint64_t seed, uint64_t first_frame, int64_t frames, uint8_t *cw_dev,
+                           uint8_t *msg_out_dev, void *stream);
 
 /*
  * 5G NR rate matching (3GPP TS 38.212 section 5.4.2: bit selection from the circular buffer, bit

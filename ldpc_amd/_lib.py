@@ -20,7 +20,7 @@ KERNEL_AUTO, KERNEL_CSR, KERNEL_QC = 0, 1, 2
 #: every symbol include/ldpc_amd.h declares
 SYMBOLS = ["ldpc_last_error", "ldpc_abi_version", "ldpc_device_count", "ldpc_code_create_csr",
            "ldpc_code_attach_qc", "ldpc_code_destroy", "ldpc_code_info", "ldpc_decode_batch",
-           "ldpc_decode_batch_host", "ldpc_decode_batch_noalloc", "ldpc_noalloc_scratch_bytes", "ldpc_count_errors", "ldpc_allreduce_counters", "ldpc_channel_llr", "ldpc_channel_llr_doppler", "ldpc_decode_segments", "ldpc_sweep_batch", "ldpc_encoder_create", "ldpc_encoder_destroy", "ldpc_encode_batch", "ldpc_rate_match", "ldpc_rate_recover",
+           "ldpc_decode_batch_host", "ldpc_decode_batch_noalloc", "ldpc_noalloc_scratch_bytes", "ldpc_count_errors", "ldpc_allreduce_counters", "ldpc_channel_llr", "ldpc_channel_llr_doppler", "ldpc_decode_segments", "ldpc_sweep_batch", "ldpc_encoder_create", "ldpc_encoder_destroy", "ldpc_encode_batch", "ldpc_encode_random", "ldpc_rate_match", "ldpc_rate_recover",
            "ldpc_last_kernel"]
 
 
@@ -121,6 +121,8 @@ def load() -> ctypes.CDLL:
     lib.ldpc_channel_llr_doppler.argtypes = [vp, i64, i64, i32, ctypes.c_double, ctypes.c_double, i32, i32,
                                              ctypes.c_double, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_double,
                                              ctypes.c_double, vp, i32, vp]
+    lib.ldpc_encode_random.restype = i32
+    lib.ldpc_encode_random.argtypes = [vp, ctypes.c_uint64, ctypes.c_uint64, i64, vp, vp, vp]
     lib.ldpc_allreduce_counters.restype = i32
     lib.ldpc_allreduce_counters.argtypes = [vp, vp, i32, vp]
     lib.ldpc_encoder_create.restype = i32

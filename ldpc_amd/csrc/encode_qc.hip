@@ -18,12 +18,19 @@
 //
 // Thread (f, z) owns position z of every block column of frame slot f; a frame's block columns
 // (codeword + temporaries) live in LDS, one byte per bit.
+//
+// Random messages (msg == NULL): the reference draws `numpy.random.randint(0, 2, k)` per frame
+// (ldpc.py:649); here message bit i of the frame with absolute index a is bit (i mod 128) of
+// Philox4x32-10(counter = (a, i / 128, 1), key = seed) - a function of (seed, frame, bit) only, so
+// that any split of a sweep into launches, ranks or GPUs sends the same messages.
 #include "extra_kernels.h"
+#include "sweep_fused.h"
 
 namespace ldpc {
 
 __global__ void __launch_bounds__(1024)
-encode_qc_kernel(EncDev e, const uint8_t *__restrict__ msg, long long frames, uint8_t *__restrict__ cw, int F)
+encode_qc_kernel(EncDev e, const uint8_t *__restrict__ msg, long long frames, uint8_t *__restrict__ cw, int F,
+                 unsigned k0, unsigned k1, unsigned long long first_frame, uint8_t *__restrict__ msg_out)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int Z = e.Z, tid = threadIdx.x;
@@ -32,13 +39,28 @@ encode_qc_kernel(EncDev e, const uint8_t *__restrict__ msg, long long frames, ui
     const int z = lane_on ? tid - f * Z : 0;
     uint8_t *xs = smem + (size_t)f * e.n_cols * Z;
     const long long k = (long long)e.k_cols * Z, n = (long long)e.nb * Z;
+    const int words = (int)((k + 127) / 128);                                        // Philox blocks per frame
+    unsigned *rnd = reinterpret_cast<unsigned *>(smem + (((size_t)F * e.n_cols * Z + 15) & ~(size_t)15));  // [F][words][4]
     const long long groups = (frames + F - 1) / F;
     for (long long grp = blockIdx.x; grp < groups; grp += gridDim.x) {
         const long long frame = grp * F + f;
         const bool active = lane_on && frame < frames;
+        if (!msg) {
+            for (int i = tid; i < F * words; i += blockDim.x) {
+                const int f2 = i / words, w = i - f2 * words;
+                const unsigned long long af = first_frame + (unsigned long long)(grp * F + f2);
+                const Philox4 r = philox4x32_10((unsigned)af, (unsigned)(af >> 32), (unsigned)w, 1u, k0, k1);
+                *reinterpret_cast<uint4 *>(rnd + (size_t)i * 4) = make_uint4(r.x, r.y, r.z, r.w);
+            }
+            __syncthreads();
+        }
         for (int j = 0; j < e.k_cols; ++j) {
-            const uint8_t b = active ? (msg[frame * k + (long long)j * Z + z] & 1) : 0;
+            const long long pos = (long long)j * Z + z;
+            uint8_t b;
+            if (msg) b = active ? (msg[frame * k + pos] & 1) : 0;
+            else b = (uint8_t)((rnd[((size_t)f * words + (pos >> 7)) * 4 + ((pos >> 5) & 3)] >> (pos & 31)) & 1u);
             if (lane_on) xs[e.info_cols[j] * Z + z] = b;
+            if (msg_out && active) msg_out[frame * k + pos] = b;
         }
         int level = -1;
         for (int s = 0; s < e.n_steps; ++s) {
@@ -63,14 +85,15 @@ encode_qc_kernel(EncDev e, const uint8_t *__restrict__ msg, long long frames, ui
 }
 
 hipError_t launch_encode_qc(const EncDev &e, const uint8_t *msg, long long frames, uint8_t *cw, int num_cus,
-                            hipStream_t stream, bool *supported)
+                            hipStream_t stream, bool *supported, unsigned long long seed, unsigned long long first_frame,
+                            uint8_t *msg_out)
 {
     *supported = false;
     if (e.Z < 1 || e.Z > 1024) return hipSuccess;
     int F = e.Z >= 256 ? 1 : 256 / e.Z;
-    size_t per_frame = (size_t)e.n_cols * e.Z;
-    while (F > 1 && F * per_frame > 64 * 1024) --F;
-    const size_t lds = F * per_frame;
+    const size_t per_frame = (size_t)e.n_cols * e.Z, rnd_bytes = (((size_t)e.k_cols * e.Z + 127) / 128) * 16;
+    while (F > 1 && F * (per_frame + rnd_bytes) > 64 * 1024) --F;
+    const size_t lds = ((F * per_frame + 15) & ~(size_t)15) + F * rnd_bytes;
     if (lds > 160 * 1024) return hipSuccess;
     *supported = true;
     const int threads = ((F * e.Z + 63) / 64) * 64;
@@ -83,7 +106,8 @@ hipError_t launch_encode_qc(const EncDev &e, const uint8_t *msg, long long frame
     long long grid = (long long)num_cus * per_cu * 2;
     if (grid > groups) grid = groups;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(encode_qc_kernel, dim3((unsigned)grid), dim3(threads), lds, stream, e, msg, frames, cw, F);
+    hipLaunchKernelGGL(encode_qc_kernel, dim3((unsigned)grid), dim3(threads), lds, stream, e, msg, frames, cw, F,
+                       (unsigned)seed, (unsigned)(seed >> 32), first_frame, msg_out);
     return hipGetLastError();
 }
 

@@ -636,7 +636,24 @@ extern "C" int32_t ldpc_encode_batch(ldpc_encoder *enc, const uint8_t *msg_dev, 
     if (!msg_dev || !cw_dev) return fail(LDPC_ERR_ARG, "NULL buffer");
     HIP_TRY(hipSetDevice(enc->device));
     bool supported = false;
-    hipError_t e = launch_encode_qc(enc->dev, msg_dev, frames, cw_dev, enc->num_cus, reinterpret_cast<hipStream_t>(stream), &supported);
+    hipError_t e = launch_encode_qc(enc->dev, msg_dev, frames, cw_dev, enc->num_cus, reinterpret_cast<hipStream_t>(stream), &supported,
+                                    0, 0, nullptr);
+    if (e != hipSuccess) return fail(LDPC_ERR_HIP, "encoder launch: %s", hipGetErrorString(e));
+    if (!supported) return fail(LDPC_ERR_UNSUPPORTED, "one frame's block columns exceed LDS");
+    return LDPC_OK;
+}
+
+extern "C" int32_t ldpc_encode_random(ldpc_encoder *enc, uint64_t seed, uint64_t first_frame, int64_t frames,
+                                      uint8_t *cw_dev, uint8_t *msg_out_dev, void *stream)
+{
+    if (!enc) return fail(LDPC_ERR_ARG, "encoder is NULL");
+    if (frames < 0) return fail(LDPC_ERR_ARG, "negative frame count");
+    if (frames == 0) return LDPC_OK;
+    if (!cw_dev) return fail(LDPC_ERR_ARG, "NULL buffer");
+    HIP_TRY(hipSetDevice(enc->device));
+    bool supported = false;
+    hipError_t e = launch_encode_qc(enc->dev, nullptr, frames, cw_dev, enc->num_cus, reinterpret_cast<hipStream_t>(stream), &supported,
+                                    seed, first_frame, msg_out_dev);
     if (e != hipSuccess) return fail(LDPC_ERR_HIP, "encoder launch: %s", hipGetErrorString(e));
     if (!supported) return fail(LDPC_ERR_UNSUPPORTED, "one frame's block columns exceed LDS");
     return LDPC_OK;

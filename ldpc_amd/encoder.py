@@ -201,6 +201,20 @@ class DeviceEncoder:
         from . import _lib
         _lib.check(self._lib.ldpc_encode_batch(self._h, msg_ptr, int(frames), cw_ptr, stream or None))
 
+    def random_codewords(self, frames: int, seed, first_frame: int = 0, device=None, want_messages: bool = False):
+        """Codewords of random messages drawn on the device (``ldpc_encode_random``): frame f gets the
+        message of absolute frame ``first_frame + f`` under ``seed``, whatever launch produces it."""
+        import torch
+        device = device or torch.device("cuda", torch.cuda.current_device())
+        cw = torch.empty((frames, self.n), dtype=torch.uint8, device=device)
+        msg = torch.empty((frames, self.k), dtype=torch.uint8, device=device) if want_messages else None
+        key = int(np.random.SeedSequence(seed).generate_state(1, dtype=np.uint64)[0])
+        from . import _lib
+        _lib.check(self._lib.ldpc_encode_random(self._h, key, int(first_frame), int(frames), cw.data_ptr(),
+                                                msg.data_ptr() if want_messages else None,
+                                                torch.cuda.current_stream().cuda_stream or None))
+        return (cw, msg) if want_messages else cw
+
     def __call__(self, msgs):
         import torch
         msgs = msgs.contiguous()

@@ -336,6 +336,8 @@ def codewords_range(code: CompiledCode, G, first: int, last: int, total: int, se
     import torch
 
     seed = list(np.atleast_1d(seed))
+    if hasattr(G, "random_codewords"):   # device encoder: messages keyed by the absolute frame number, one launch
+        return G.random_codewords(last - first, seed + [77], first_frame=first, device=device)
     parts = []
     for c in range(first // SWEEP_CHUNK, (last + SWEEP_CHUNK - 1) // SWEEP_CHUNK):
         c0 = c * SWEEP_CHUNK

@@ -64,3 +64,19 @@ def channel_llr(ref, frames, n, sigma2, gain, plus_is_bit, prefix_len, prefix_ll
     llr = f32(gain) * (x + f32(np.sqrt(sigma2)) * z)
     llr[:, :prefix_len] = f32(prefix_llr)
     return llr
+
+
+def random_message_bits(frames, k, seed, first_frame=0):
+    """[frames, k] uint8 message bits of ``ldpc_encode_random``: bit i of frame a is bit (i mod 128) of
+    Philox4x32-10(counter = (a lo, a hi, i // 128, 1), key = seed); word order x, y, z, w, least
+    significant bit first."""
+    words = (k + 127) // 128
+    af = (np.arange(frames, dtype=np.uint64) + np.uint64(first_frame))[:, None]
+    w = np.arange(words, dtype=np.uint64)[None, :]
+    c0 = np.broadcast_to(af & MASK, (frames, words))
+    c1 = np.broadcast_to(af >> np.uint64(32), (frames, words))
+    c2 = np.broadcast_to(w, (frames, words))
+    out = philox4x32_10(c0, c1, c2, np.ones((frames, words), np.uint64), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    u = np.stack(out, axis=-1).astype(np.uint32)                      # [frames, words, 4]
+    bits = (u[..., None] >> np.arange(32, dtype=np.uint32)) & 1       # [frames, words, 4, 32]
+    return bits.reshape(frames, words * 128)[:, :k].astype(np.uint8)

@@ -104,3 +104,36 @@ def test_encoder_feeds_the_sweep_and_rejects_bad_schedules():
     torch.cuda.synchronize()
     assert out.cpu().numpy().tolist() == [[1, 0, 1, 1] * 3]
     lib.ldpc_encoder_destroy(h)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["ccsds512", "wifi648", "nr_bg1_z384"])
+def test_random_messages_on_the_device(name):
+    """ldpc_encode_random: the messages are this build's Philox stream (numpy restatement in
+    oracle/channel_oracle.py), a function of (seed, absolute frame, bit) - so two launches that split
+    a range of frames give what one launch gives - and the codewords are their encodings."""
+    import torch
+    from oracle import channel_oracle as co
+    dev = torch.device("cuda", 0)
+    code, G, s = _schedule(name)
+    enc = encoder.DeviceEncoder(s)
+    frames = 37 if code.n > 4096 else 1001
+    cw, msg = enc.random_codewords(frames, [9, 4], first_frame=5, device=dev, want_messages=True)
+    key = int(np.random.SeedSequence([9, 4]).generate_state(1, dtype=np.uint64)[0])
+    want = co.random_message_bits(frames, s.k, key, first_frame=5)
+    assert np.array_equal(msg.cpu().numpy(), want)
+    assert np.array_equal(cw.cpu().numpy(), s.run_host(want))
+    assert 0.45 < want.mean() < 0.55
+    a = enc.random_codewords(frames - 10, [9, 4], first_frame=5, device=dev)
+    b = enc.random_codewords(10, [9, 4], first_frame=5 + frames - 10, device=dev)
+    assert torch.equal(torch.cat([a, b]), cw)
+    # a sweep fed by the device encoder does not depend on how it is cut into launches
+    if name == "ccsds512":
+        from ldpc_amd import config, sweep
+        one = sweep.ber_sweep(code, enc, config.R1, [0.0], 50_000, dev, np.float32, seed=3, batch=1 << 18)
+        cut = sweep.ber_sweep(code, enc, config.R1, [0.0], 50_000, dev, np.float32, seed=3, batch=1 << 14)
+        two = [sweep.ber_sweep(code, enc, config.R1, [0.0], 50_000, dev, np.float32, seed=3, rank=r, world=2, reduce=False)[0] for r in (0, 1)]
+        assert one == cut
+        for k in ("frames", "not_converged", "bit_errors", "iterations"):
+            assert one[0][k] == two[0][k] + two[1][k]
+        assert 0 < one[0]["not_converged"] < 50_000
