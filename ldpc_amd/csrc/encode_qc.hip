@@ -84,12 +84,76 @@ encode_qc_kernel(EncDev e, const uint8_t *__restrict__ msg, long long frames, ui
     }
 }
 
+// Dense schedules of small circulants (Z <= 64: the CCSDS generator, 115 taps per row): a block
+// column is a Z-bit mask - the ballot of its bits over the wave - and one step input is
+//     out[z] ^= XOR over the taps s of col[(z + s) mod Z]  =  parity(popcount(col & rotl_Z(taps, z))),
+// eight vector instructions per (output, input) column pair instead of about six per tap.  One frame
+// per wave; masks of the block columns live in LDS (read back as broadcasts).  taps[step][column] is
+// the Z-bit mask of the step's shifts for that source column (0 = not an input).
+__global__ void __launch_bounds__(64)
+encode_dense_kernel(EncDev e, const unsigned long long *__restrict__ taps, const uint8_t *__restrict__ msg,
+                    long long frames, uint8_t *__restrict__ cw, unsigned k0, unsigned k1, unsigned long long first_frame,
+                    uint8_t *__restrict__ msg_out)
+{
+    __shared__ unsigned long long col_mask[256];
+    __shared__ __align__(16) unsigned rnd[4 * 32];
+    const int Z = e.Z, z = threadIdx.x;
+    const bool lane_on = z < Z;
+    const unsigned long long zmask = Z >= 64 ? ~0ull : ((1ull << Z) - 1ull);
+    const long long k = (long long)e.k_cols * Z, n = (long long)e.nb * Z;
+    const int words = (int)((k + 127) / 128);
+    for (long long frame = blockIdx.x; frame < frames; frame += gridDim.x) {
+        if (!msg) {
+            const unsigned long long af = first_frame + (unsigned long long)frame;
+            for (int w = z; w < words; w += 64) {
+                const Philox4 r = philox4x32_10((unsigned)af, (unsigned)(af >> 32), (unsigned)w, 1u, k0, k1);
+                *reinterpret_cast<uint4 *>(rnd + w * 4) = make_uint4(r.x, r.y, r.z, r.w);
+            }
+        }
+        for (int j = 0; j < e.k_cols; ++j) {
+            const long long pos = (long long)j * Z + z;
+            unsigned b = 0;
+            if (lane_on) b = msg ? (msg[frame * k + pos] & 1u) : ((rnd[(pos >> 7) * 4 + ((pos >> 5) & 3)] >> (pos & 31)) & 1u);
+            const unsigned long long m = __ballot(b != 0);
+            const int c = e.info_cols[j];
+            if (z == 0) col_mask[c] = m;
+            if (lane_on) {
+                cw[frame * n + (long long)c * Z + z] = (uint8_t)b;
+                if (msg_out) msg_out[frame * k + pos] = (uint8_t)b;
+            }
+        }
+        for (int s = 0; s < e.n_steps; ++s) {
+            unsigned acc = 0;
+            for (int c = 0; c < e.n_cols; ++c) {
+                const unsigned long long t = taps[(size_t)s * e.n_cols + c];  // the same for every lane
+                if (t == 0ull) continue;
+                unsigned long long r = (t << z) | (t >> ((Z - z) & 63));
+                if (z == 0) r = t;
+                r &= zmask & col_mask[c];
+                acc += (unsigned)__popcll(r);
+            }
+            const unsigned long long m = __ballot(lane_on && (acc & 1u));
+            const int c = e.step_out[s];
+            if (z == 0) col_mask[c] = m;
+            if (lane_on && c < e.nb) cw[frame * n + (long long)c * Z + z] = (uint8_t)(acc & 1u);
+        }
+    }
+}
+
 hipError_t launch_encode_qc(const EncDev &e, const uint8_t *msg, long long frames, uint8_t *cw, int num_cus,
                             hipStream_t stream, bool *supported, unsigned long long seed, unsigned long long first_frame,
-                            uint8_t *msg_out)
+                            uint8_t *msg_out, const unsigned long long *dense_taps)
 {
     *supported = false;
     if (e.Z < 1 || e.Z > 1024) return hipSuccess;
+    if (dense_taps) {  // dense schedule of small circulants: one frame per wave, ballot masks
+        *supported = true;
+        long long grid = (long long)num_cus * 32;
+        if (grid > frames) grid = frames;
+        hipLaunchKernelGGL(encode_dense_kernel, dim3((unsigned)grid), dim3(64), 0, stream, e, dense_taps, msg, frames, cw,
+                           (unsigned)seed, (unsigned)(seed >> 32), first_frame, msg_out);
+        return hipGetLastError();
+    }
     int F = e.Z >= 256 ? 1 : 256 / e.Z;
     const size_t per_frame = (size_t)e.n_cols * e.Z, rnd_bytes = (((size_t)e.k_cols * e.Z + 127) / 128) * 16;
     while (F > 1 && F * (per_frame + rnd_bytes) > 64 * 1024) --F;

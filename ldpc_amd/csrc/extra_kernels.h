@@ -20,7 +20,9 @@ struct EncDev {
 };
 hipError_t launch_encode_qc(const EncDev &e, const uint8_t *msg, long long frames, uint8_t *cw, int num_cus,
                             hipStream_t stream, bool *supported, unsigned long long seed, unsigned long long first_frame,
-                            uint8_t *msg_out);  // msg == NULL: random messages keyed by (seed, first_frame + frame)
+                            uint8_t *msg_out, const unsigned long long *dense_taps);
+// msg == NULL: random messages keyed by (seed, first_frame + frame); dense_taps != NULL: the ballot-mask
+// kernel for dense schedules with Z <= 64, taps[step][column] = Z-bit mask of the step's shifts
 
 // rate_match.hip: 5G NR bit selection / interleaving and its inverse on LLRs (TS 38.212 5.4.2)
 hipError_t launch_rate_match(const ldpc_rate_match_config &c, const uint8_t *cw, long long cw_stride, long long frames,

@@ -556,6 +556,7 @@ struct ldpc_encoder {
     int device = 0, num_cus = 0;
     EncDev dev{};
     int *d_ints = nullptr;  // one allocation: info_cols | step_out | step_ptr | step_level | terms
+    unsigned long long *d_taps = nullptr;  // dense schedules with Z <= 64: [n_steps][n_cols] tap masks, else NULL
 };
 
 extern "C" int32_t ldpc_encoder_create(int32_t Z, int32_t n_cols, int32_t nb, int32_t k_cols, const int32_t *info_cols,
@@ -616,6 +617,26 @@ extern "C" int32_t ldpc_encoder_create(int32_t Z, int32_t n_cols, int32_t nb, in
     d.step_ptr = d.step_out + n_steps;
     d.step_level = d.step_ptr + n_steps + 1;
     d.terms = reinterpret_cast<const unsigned *>(d.step_level + n_steps);
+    // a schedule with many taps per (output, input) column pair and Z <= 64 runs on ballot masks
+    if (Z <= 64 && n_cols <= 256 && n_steps > 0) {
+        std::vector<unsigned long long> taps((size_t)n_steps * n_cols, 0ull);
+        long long pairs = 0;
+        for (int s = 0; s < n_steps; ++s)
+            for (int t = step_ptr[s]; t < step_ptr[s + 1]; ++t) {
+                unsigned long long &m = taps[(size_t)s * n_cols + term_col[t]];
+                pairs += m == 0ull;
+                m ^= 1ull << term_shift[t];  // a shift listed twice cancels, as it does in the XOR of the terms
+            }
+        if (pairs > 0 && n_terms >= 4 * pairs) {
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&enc->d_taps), taps.size() * sizeof(unsigned long long)));
+            e = hipMemcpy(enc->d_taps, taps.data(), taps.size() * sizeof(unsigned long long), hipMemcpyHostToDevice);
+            if (e != hipSuccess) {
+                (void)hipFree(enc->d_taps);
+                (void)hipFree(enc->d_ints);
+                return fail(LDPC_ERR_HIP, "encoder tables: %s", hipGetErrorString(e));
+            }
+        }
+    }
     *out = enc.release();
     return LDPC_OK;
 }
@@ -625,6 +646,7 @@ extern "C" void ldpc_encoder_destroy(ldpc_encoder *enc)
     if (!enc) return;
     (void)hipSetDevice(enc->device);
     if (enc->d_ints) (void)hipFree(enc->d_ints);
+    if (enc->d_taps) (void)hipFree(enc->d_taps);
     delete enc;
 }
 
@@ -637,7 +659,7 @@ extern "C" int32_t ldpc_encode_batch(ldpc_encoder *enc, const uint8_t *msg_dev, 
     HIP_TRY(hipSetDevice(enc->device));
     bool supported = false;
     hipError_t e = launch_encode_qc(enc->dev, msg_dev, frames, cw_dev, enc->num_cus, reinterpret_cast<hipStream_t>(stream), &supported,
-                                    0, 0, nullptr);
+                                    0, 0, nullptr, enc->d_taps);
     if (e != hipSuccess) return fail(LDPC_ERR_HIP, "encoder launch: %s", hipGetErrorString(e));
     if (!supported) return fail(LDPC_ERR_UNSUPPORTED, "one frame's block columns exceed LDS");
     return LDPC_OK;
@@ -653,7 +675,7 @@ extern "C" int32_t ldpc_encode_random(ldpc_encoder *enc, uint64_t seed, uint64_t
     HIP_TRY(hipSetDevice(enc->device));
     bool supported = false;
     hipError_t e = launch_encode_qc(enc->dev, nullptr, frames, cw_dev, enc->num_cus, reinterpret_cast<hipStream_t>(stream), &supported,
-                                    seed, first_frame, msg_out_dev);
+                                    seed, first_frame, msg_out_dev, enc->d_taps);
     if (e != hipSuccess) return fail(LDPC_ERR_HIP, "encoder launch: %s", hipGetErrorString(e));
     if (!supported) return fail(LDPC_ERR_UNSUPPORTED, "one frame's block columns exceed LDS");
     return LDPC_OK;

@@ -60,3 +60,10 @@ conv = torch.ones((frames,), dtype=torch.uint8, device=dev)
 ctr = torch.zeros((5,), dtype=torch.int64, device=dev)
 t = timed(lambda: dec.count_errors_device(hard.data_ptr(), cw.data_ptr(), enc.n, iters.data_ptr(), conv.data_ptr(), frames, ctr.data_ptr(), stream=stream))
 print(f"count_errors      {frames * (2 * enc.n + 5) / t / 1e9:8.1f} GB/s  {t * 1e3:.3f} ms")
+# the CCSDS encoder (dense generator circulants: ballot-mask kernel), random messages drawn on the device
+c2 = codes.load_packaged("ccsds512")
+e2 = encoder.device_encoder(c2, codes.load_packaged_generator("ccsds512"))
+fr2 = 1 << 20
+cw2 = torch.empty((fr2, c2.n), dtype=torch.uint8, device=dev)
+t = timed(lambda: _lib.check(lib.ldpc_encode_random(e2._h, 5, 0, fr2, cw2.data_ptr(), None, stream or None)))
+print(f"encode ccsds rnd  {fr2 * c2.n / t / 1e9:8.1f} GB/s  {t * 1e3:.3f} ms  {fr2 * 256 / t / 1e9:.1f} Gbit/s info")
