@@ -177,7 +177,15 @@ __device__ __forceinline__ unsigned ln_addr(unsigned zl, unsigned zbP, unsigned 
 {
     if constexpr (S == 0) return zbP + (unsigned)(LY::P_OFF + CI * LY::VEC);
     else {
-        const unsigned base = zl >= (unsigned)(LY::VEC - S * LY::ST) ? zbP : zbPW;
+        unsigned base;  // = zl >= VEC - S ST ? zbP : zbPW
+        if constexpr (LY::ST == 4) {
+            // written out with the threshold as a literal of the compare: the compiler keeps thresholds in
+            // scalar registers (one more instruction each) and separates compare and select by wait states
+            asm("v_cmp_le_u32_e32 vcc, %3, %4\n\tv_cndmask_b32_e32 %0, %1, %2, vcc"
+                : "=v"(base) : "v"(zbPW), "v"(zbP), "i"(LY::VEC - S * LY::ST), "v"(zl) : "vcc");
+        } else {  // double: the blocks would cost the compiler's schedule more registers than the kernel has
+            base = zl >= (unsigned)(LY::VEC - S * LY::ST) ? zbP : zbPW;
+        }
         return base + (unsigned)(LY::P_OFF + CI * LY::VEC + S * LY::ST - LY::VEC);
     }
 }
@@ -459,6 +467,7 @@ lnms_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__r
                             if constexpr (p != PP) {
                                 constexpr int bc = C::row_col[e0 + p], s = C::row_shift[e0 + p];
                                 v[p] = lds_get<T>(ln_addr<LY, PL::lds_index(bc), s>(zl, zbP, zbPW));
+                                if constexpr (ST == 4) __builtin_amdgcn_sched_barrier(0);  // as in the sweep below
                             }
                         });
                         unsigned par = 0;
@@ -518,8 +527,8 @@ lnms_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__r
                         load_state(br, Ao, Bo, w);
                         const int idx_old = (int)((w >> 24) & 31u);
                         const unsigned wp = w ^ (unsigned)((int)w >> 31);  // bit D-1-p: sign of the old message on edge p
-                        T m1 = Lim<T>::inf(), m2 = Lim<T>::inf();
-                        unsigned sq = 0;
+                        T m1, m2;
+                        unsigned sq;
                         unsigned zl = zb;
                         asm volatile("" : "+v"(zl));  // as above: hundreds of hoisted addresses would spill
                         // all posteriors of the row are requested first, so that the row pays one LDS round
@@ -531,6 +540,7 @@ lnms_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__r
                                 constexpr int bc = C::row_col[e0 + p], s = C::row_shift[e0 + p];
                                 off[p] = ln_addr<LY, PL::lds_index(bc), s>(zl, zbP, zbPW);
                                 q[p] = lds_get<T>(off[p]);
+                                if constexpr (ST == 4) __builtin_amdgcn_sched_barrier(0);  // address, read, address, read: two address blocks in a row cost a wait state
                             }
                         });
                         // bit 31 of ws: sign of the old message on the current edge (one doubling per edge
@@ -539,15 +549,10 @@ lnms_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__r
                         static_for<0, D>([&](auto p) {
                             if constexpr (p == PP) {
                                 q[p] = lp;  // a variable of degree one always sends its channel LLR
+                                SNum<T>::template edge_in_given<p == 0, (p + 1 < D)>(q[p], ws, m1, m2, sq, Lim<T>::inf());
                             } else {
-                                // previous message of this edge: magnitude B for the old argmin, else A
-                                const T mag = idx_old == p ? Bo : Ao;
-                                q[p] = q[p] - SNum<T>::with_sign(mag, ws);
+                                SNum<T>::template edge_in<p, p == 0, (p + 1 < D)>(q[p], (unsigned)idx_old, Ao, Bo, ws, m1, m2, sq, Lim<T>::inf());
                             }
-                            if constexpr (p + 1 < D) asm("v_add_u32 %0, %0, %0" : "+v"(ws));  // the compiler would turn `ws += ws` back into shifts
-                            m2 = SNum<T>::second(m1, m2, q[p]);
-                            m1 = SNum<T>::min_abs(m1, q[p]);
-                            sq = (sq << 1) | (SNum<T>::sign_word(q[p]) >> 31);
                         });
                         const unsigned px = (unsigned)__popc(sq) << 31;  // sign parity of the inputs
                         const T An = g.scale * m1, Bn = g.scale * m2;
@@ -556,11 +561,12 @@ lnms_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__r
                         unsigned privbit = 0;
                         static_for<0, D>([&](auto pp) {
                             constexpr int p = D - 1 - pp;
-                            const T mag = SNum<T>::pick_min(q[p], m1, Anp, Bnp, minbits);
-                            if constexpr (p != PP)
-                                lds_put<T>(off[p], q[p] + SNum<T>::flip_sign(mag, SNum<T>::sign_word(q[p]) & 0x80000000u));
-                            else if (want_bits)
-                                privbit = hard_bit<1>(q[p] + SNum<T>::flip_sign(mag, SNum<T>::sign_word(q[p]) & 0x80000000u)) << 30;
+                            const T pn = SNum<T>::pick_add(q[p], m1, Anp, Bnp, minbits);  // the variable's new posterior
+                            if constexpr (p != PP) {
+                                lds_put<T>(off[p], pn);
+                                if constexpr (ST == 4) __builtin_amdgcn_sched_barrier(0);  // block, write, block, write
+                            }
+                            else if (want_bits) privbit = hard_bit<1>(pn) << 30;
                         });
                         const int idx = __builtin_ctz(minbits);  // the first minimum; some bit is always set
                         const unsigned wn = sq | ((unsigned)idx << 24) | px | privbit;

@@ -41,6 +41,59 @@ template <> struct SNum<float> {
             : "=&v"(mag), "+v"(bits) : "v"(q), "v"(m1), "v"(a), "v"(b) : "vcc");
         return mag;
     }
+    // q + sign(q) * (|q| == m1 ? b : a), the comparison booked in `bits` as above.  One block: the
+    // compiler puts a wait state between such a block and a vector instruction that reads its result
+    // at once, and here the only reader left is an LDS store.
+    __device__ static __forceinline__ float pick_add(float q, float m1, float a, float b, unsigned &bits) {
+        float out, t;
+        asm("v_cmp_eq_f32_e64 vcc, |%3|, %4\n\tv_cndmask_b32_e32 %1, %5, %6, vcc\n\tv_addc_co_u32_e32 %2, vcc, %2, %2, vcc\n\t"
+            "v_bitop3_b32 %1, %3, %1, %7 bitop3:0x6c\n\tv_add_f32_e32 %0, %3, %1"
+            : "=v"(out), "=&v"(t), "+v"(bits) : "v"(q), "v"(m1), "v"(a), "v"(b), "s"(0x80000000u) : "vcc");
+        return out;
+    }
+    // One input edge of a layered check as one block: take the edge's previous message (magnitude b
+    // if this edge held the minimum last time, else a; sign in bit 31 of ws) off the posterior q,
+    // advance the sign word to the next edge, and book |q| and sign(q) in the running smallest /
+    // second smallest (m1 <= m2) and in the sign word sq.  FIRST: the check's first edge (m1, m2, sq
+    // start here; inf = a register that holds +infinity); MORE: another edge follows.
+#define LDPC_EDGE_OLD "v_cmp_eq_u32_e32 vcc, %[p], %[idx]\n\tv_cndmask_b32_e32 %[t], %[a], %[b], vcc\n\t" \
+                      "v_and_or_b32 %[t], %[ws], %[S], %[t]\n\tv_sub_f32_e32 %[q], %[q], %[t]\n\t"
+#define LDPC_EDGE_STEP "v_add_u32 %[ws], %[ws], %[ws]\n\t"
+#define LDPC_EDGE_BOOK "v_med3_f32 %[m2], %[m1], %[m2], |%[q]|\n\tv_min_f32 %[m1], %[m1], |%[q]|\n\t" \
+                       "v_alignbit_b32 %[sq], %[sq], %[q], 31"
+#define LDPC_EDGE_BOOK1 "v_med3_f32 %[m2], %[inf], %[inf], |%[q]|\n\tv_min_f32 %[m1], %[inf], |%[q]|\n\t" \
+                        "v_lshrrev_b32_e32 %[sq], 31, %[q]"
+    template <int P, bool FIRST, bool MORE>
+    __device__ static __forceinline__ void edge_in(float &q, unsigned idx_old, float a, float b, unsigned &ws, float &m1,
+                                                   float &m2, unsigned &sq, float inf) {
+        float t;
+        static_assert(!FIRST || MORE, "a check has at least two edges");
+        if constexpr (FIRST)
+            asm(LDPC_EDGE_OLD LDPC_EDGE_STEP LDPC_EDGE_BOOK1
+                : [q] "+v"(q), [t] "=&v"(t), [ws] "+v"(ws), [m1] "=&v"(m1), [m2] "=&v"(m2), [sq] "=v"(sq)
+                : [p] "i"(P), [idx] "v"(idx_old), [a] "v"(a), [b] "v"(b), [S] "s"(0x80000000u), [inf] "v"(inf) : "vcc");
+        else if constexpr (MORE)
+            asm(LDPC_EDGE_OLD LDPC_EDGE_STEP LDPC_EDGE_BOOK
+                : [q] "+v"(q), [t] "=&v"(t), [ws] "+v"(ws), [m1] "+v"(m1), [m2] "+v"(m2), [sq] "+v"(sq)
+                : [p] "i"(P), [idx] "v"(idx_old), [a] "v"(a), [b] "v"(b), [S] "s"(0x80000000u) : "vcc");
+        else
+            asm(LDPC_EDGE_OLD LDPC_EDGE_BOOK
+                : [q] "+v"(q), [t] "=&v"(t), [m1] "+v"(m1), [m2] "+v"(m2), [sq] "+v"(sq)
+                : [p] "i"(P), [idx] "v"(idx_old), [a] "v"(a), [b] "v"(b), [ws] "v"(ws), [S] "s"(0x80000000u) : "vcc");
+    }
+    // the same for an edge whose input q is given (no previous message to take off)
+    template <bool FIRST, bool MORE>
+    __device__ static __forceinline__ void edge_in_given(float q, unsigned &ws, float &m1, float &m2, unsigned &sq, float inf) {
+        if constexpr (MORE) asm("v_add_u32 %0, %0, %0" : "+v"(ws));
+        if constexpr (FIRST)
+            asm(LDPC_EDGE_BOOK1 : [m1] "=&v"(m1), [m2] "=&v"(m2), [sq] "=v"(sq) : [q] "v"(q), [inf] "v"(inf));
+        else
+            asm(LDPC_EDGE_BOOK : [m1] "+v"(m1), [m2] "+v"(m2), [sq] "+v"(sq) : [q] "v"(q));
+    }
+#undef LDPC_EDGE_OLD
+#undef LDPC_EDGE_STEP
+#undef LDPC_EDGE_BOOK
+#undef LDPC_EDGE_BOOK1
 };
 template <> struct SNum<double> {
     typedef double2 Pair;
@@ -69,6 +122,24 @@ template <> struct SNum<double> {
             : "v"(q), "v"(m1), "v"(__double2loint(a)), "v"(__double2hiint(a)), "v"(__double2loint(b)), "v"(__double2hiint(b))
             : "vcc");
         return __hiloint2double(hi, lo);
+    }
+    template <int P, bool FIRST, bool MORE>
+    __device__ static __forceinline__ void edge_in(double &q, unsigned idx_old, double a, double b, unsigned &ws, double &m1,
+                                                   double &m2, unsigned &sq, double inf) {
+        q = q - with_sign((int)idx_old == P ? b : a, ws);
+        edge_in_given<FIRST, MORE>(q, ws, m1, m2, sq, inf);
+    }
+    template <bool FIRST, bool MORE>
+    __device__ static __forceinline__ void edge_in_given(double q, unsigned &ws, double &m1, double &m2, unsigned &sq, double inf) {
+        if constexpr (MORE) asm("v_add_u32 %0, %0, %0" : "+v"(ws));  // the compiler would turn `ws += ws` into a shift
+        if constexpr (FIRST) { m1 = inf; m2 = inf; sq = 0; }
+        m2 = second(m1, m2, q);
+        m1 = min_abs(m1, q);
+        sq = (sq << 1) | (sign_word(q) >> 31);
+    }
+    __device__ static __forceinline__ double pick_add(double q, double m1, double a, double b, unsigned &bits) {
+        const double mag = pick_min(q, m1, a, b, bits);
+        return q + flip_sign(mag, sign_word(q) & 0x80000000u);
     }
 };
 
