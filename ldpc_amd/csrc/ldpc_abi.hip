@@ -57,6 +57,7 @@ struct ldpc_code {
     // device staging of ldpc_decode_batch_host (inputs and results of one call); grows, never shrinks
     char *host_stage = nullptr;
     size_t host_stage_bytes = 0;
+    std::vector<char> host_bounce;  // host side of the small-result copy of ldpc_decode_batch_host
     Scratch &workspace_for(hipStream_t stream)
     {
         for (auto &w : workspaces)
@@ -446,10 +447,22 @@ extern "C" int32_t ldpc_decode_batch_host(ldpc_code *c, const ldpc_decode_config
                                reinterpret_cast<uint8_t *>(d_hard), reinterpret_cast<int32_t *>(d_it),
                                reinterpret_cast<uint8_t *>(d_cv), posterior ? d_post : nullptr, nullptr);
         if (rc == LDPC_OK) {
-            e = hipDeviceSynchronize();
-            if (e == hipSuccess) e = hipMemcpy(hard, d_hard, cells, hipMemcpyDeviceToHost);
-            if (e == hipSuccess) e = hipMemcpy(iters, d_it, (size_t)frames * 4, hipMemcpyDeviceToHost);
-            if (e == hipSuccess) e = hipMemcpy(converged, d_cv, (size_t)frames, hipMemcpyDeviceToHost);
+            // hard | iters | converged lie next to each other in the staging area: a frame-at-a-time caller
+            // (the reference-shaped classes) gets them back in one copy instead of three
+            const size_t span = (size_t)(d_cv - d_hard) + (size_t)frames;
+            if (span <= (size_t)1 << 20) {
+                c->host_bounce.resize(span);
+                e = hipMemcpy(c->host_bounce.data(), d_hard, span, hipMemcpyDeviceToHost);  // also waits for the kernel
+                if (e == hipSuccess) {
+                    memcpy(hard, c->host_bounce.data(), cells);
+                    memcpy(iters, c->host_bounce.data() + (d_it - d_hard), (size_t)frames * 4);
+                    memcpy(converged, c->host_bounce.data() + (d_cv - d_hard), (size_t)frames);
+                }
+            } else {
+                e = hipMemcpy(hard, d_hard, cells, hipMemcpyDeviceToHost);
+                if (e == hipSuccess) e = hipMemcpy(iters, d_it, (size_t)frames * 4, hipMemcpyDeviceToHost);
+                if (e == hipSuccess) e = hipMemcpy(converged, d_cv, (size_t)frames, hipMemcpyDeviceToHost);
+            }
             if (e == hipSuccess && posterior) e = hipMemcpy(posterior, d_post, post_b, hipMemcpyDeviceToHost);
         }
     }
@@ -618,7 +631,8 @@ extern "C" int32_t ldpc_encoder_create(int32_t Z, int32_t n_cols, int32_t nb, in
     d.step_level = d.step_ptr + n_steps + 1;
     d.terms = reinterpret_cast<const unsigned *>(d.step_level + n_steps);
     // a schedule with many taps per (output, input) column pair and Z <= 64 runs on ballot masks
-    if (Z <= 64 && n_cols <= 256 && n_steps > 0) {
+    // (its kernel holds 256 column masks and the random words of 4096 message bits)
+    if (Z <= 64 && n_cols <= 256 && (long long)k_cols * Z <= 4096 && n_steps > 0) {
         std::vector<unsigned long long> taps((size_t)n_steps * n_cols, 0ull);
         long long pairs = 0;
         for (int s = 0; s < n_steps; ++s)
