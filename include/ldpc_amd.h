@@ -266,7 +266,8 @@ int32_t ldpc_channel_llr_doppler(const uint8_t *ref_dev, int64_t ref_stride, int
  * (checked).  ldpc_amd/encoder.py derives schedules from a parity-check matrix with 5G NR / 802.11n
  * parity structure or from a block-circulant systematic generator.
  * ldpc_encode_batch: msg_dev [frames, k_cols * Z] bytes (bit 0 of each), cw_dev [frames, nb * Z]
- * bytes of 0 / 1; enqueued on `stream`.
+ * bytes of 0 / 1; enqueued on `stream`.  device: HIP device that holds the tables and runs the
+ * launches (the buffers must be its own); negative = the calling thread's current device.
  */
 typedef struct ldpc_encoder ldpc_encoder;
 int32_t ldpc_encoder_create(int32_t Z, int32_t n_cols, int32_t nb, int32_t k_cols, const int32_t *info_cols,

@@ -606,6 +606,7 @@ extern "C" int32_t ldpc_encoder_create(int32_t Z, int32_t n_cols, int32_t nb, in
         if (known_at[c] == -2) return fail(LDPC_ERR_ARG, "codeword column %d is never produced", c);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(LDPC_ERR_NO_DEVICE, "no HIP device visible");
+    if (device < 0) HIP_TRY(hipGetDevice(&device));  // the calling thread's current device, as ldpc_code_create_csr takes it
     if (device < 0 || device >= ndev) return fail(LDPC_ERR_ARG, "device %d out of range", device);
     HIP_TRY(hipSetDevice(device));
     std::unique_ptr<ldpc_encoder> enc(new ldpc_encoder);

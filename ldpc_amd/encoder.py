@@ -180,7 +180,7 @@ class DeviceEncoder:
 
     on_device = True
 
-    def __init__(self, schedule: Schedule, device: int = 0):
+    def __init__(self, schedule: Schedule, device: int = -1):
         from . import _lib
         self.schedule = schedule
         self.k, self.n = schedule.k, schedule.n
@@ -230,6 +230,6 @@ class DeviceEncoder:
             h.value = None   # (module globals may already be gone at interpreter shutdown)
 
 
-def device_encoder(code: CompiledCode, G: Optional[np.ndarray] = None, device: int = 0) -> Optional[DeviceEncoder]:
+def device_encoder(code: CompiledCode, G: Optional[np.ndarray] = None, device: int = -1) -> Optional[DeviceEncoder]:
     s = schedule_for(code, G)
     return None if s is None else DeviceEncoder(s, device)
