@@ -20,46 +20,9 @@
 // ordered sums of the others.  Magnitudes are clamped (channel values and check outputs to 2000) so
 // that no sum of up to 30 messages leaves the half-precision range.
 #include "spec_common.h"
+#include "half2_ops.h"
 
 namespace ldpc {
-
-typedef unsigned h2;  // two half-precision numbers: frame 2p in the low half, frame 2p + 1 in the high half
-
-constexpr unsigned kAbsMask = 0x7fff7fffu, kSignMask = 0x80008000u;
-constexpr float kHalfClamp = 2000.0f;
-constexpr h2 kHalfClamp2 = 0x67d067d0u;   // 2000.0 twice
-constexpr h2 kHalfMax2 = 0x7bff7bffu;     // 65504 twice: "no input yet"
-
-__device__ __forceinline__ h2 pk_min(h2 a, h2 b) { h2 d; asm("v_pk_min_f16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
-__device__ __forceinline__ h2 pk_max(h2 a, h2 b) { h2 d; asm("v_pk_max_f16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
-__device__ __forceinline__ h2 pk_add(h2 a, h2 b) { h2 d; asm("v_pk_add_f16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
-__device__ __forceinline__ h2 pk_sub(h2 a, h2 b)
-{
-    h2 d;
-    asm("v_pk_add_f16 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
-    return d;
-}
-__device__ __forceinline__ h2 pk_mul(h2 a, h2 b) { h2 d; asm("v_pk_mul_f16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
-// c - a * b
-__device__ __forceinline__ h2 pk_fnma(h2 a, h2 b, h2 c)
-{
-    h2 d;
-    asm("v_pk_fma_f16 %0, %1, %2, %3 neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
-}
-__device__ __forceinline__ h2 pack_half2(float lo, float hi)
-{
-    lo = __builtin_amdgcn_fmed3f(lo, -kHalfClamp, kHalfClamp);
-    hi = __builtin_amdgcn_fmed3f(hi, -kHalfClamp, kHalfClamp);
-    typedef __fp16 v2h __attribute__((ext_vector_type(2)));
-    const v2h p = __builtin_amdgcn_cvt_pkrtz(lo, hi);
-    return *reinterpret_cast<const h2 *>(&p);
-}
-// "value > 0" of one half (hard decision `0 if b > 0 else 1`, bpsk.py:240-243)
-__device__ __forceinline__ bool half_positive(h2 v, int h)
-{
-    return h ? (int)v > 0xffff : ((int)(v << 16) > 0);
-}
 
 template <class C, int F>
 struct HalfLayout {

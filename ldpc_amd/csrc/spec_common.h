@@ -52,46 +52,40 @@ template <> struct SNum<float> {
         return out;
     }
     // One input edge of a layered check as one block: take the edge's previous message (magnitude b
-    // if this edge held the minimum last time, else a; sign in bit 31 of ws) off the posterior q,
-    // advance the sign word to the next edge, and book |q| and sign(q) in the running smallest /
-    // second smallest (m1 <= m2) and in the sign word sq.  FIRST: the check's first edge (m1, m2, sq
-    // start here; inf = a register that holds +infinity); MORE: another edge follows.
+    // if this edge held the minimum last time, else a; sign in bit 31 of ws) off the posterior q and
+    // book |q| and sign(q) in the running smallest / second smallest (m1 <= m2) and in the sign word.
+    // ws is ONE word for both sets of signs: the previous messages' signs leave it at the top, one per
+    // edge, while the signs of the new inputs enter at the bottom (a funnel shift by one), so after
+    // the check's last edge it holds the new signs, first edge highest.  FIRST: the check's first
+    // edge (m1, m2 start here; inf = a register that holds +infinity).
 #define LDPC_EDGE_OLD "v_cmp_eq_u32_e32 vcc, %[p], %[idx]\n\tv_cndmask_b32_e32 %[t], %[a], %[b], vcc\n\t" \
                       "v_and_or_b32 %[t], %[ws], %[S], %[t]\n\tv_sub_f32_e32 %[q], %[q], %[t]\n\t"
-#define LDPC_EDGE_STEP "v_add_u32 %[ws], %[ws], %[ws]\n\t"
 #define LDPC_EDGE_BOOK "v_med3_f32 %[m2], %[m1], %[m2], |%[q]|\n\tv_min_f32 %[m1], %[m1], |%[q]|\n\t" \
-                       "v_alignbit_b32 %[sq], %[sq], %[q], 31"
+                       "v_alignbit_b32 %[ws], %[ws], %[q], 31"
 #define LDPC_EDGE_BOOK1 "v_med3_f32 %[m2], %[inf], %[inf], |%[q]|\n\tv_min_f32 %[m1], %[inf], |%[q]|\n\t" \
-                        "v_lshrrev_b32_e32 %[sq], 31, %[q]"
-    template <int P, bool FIRST, bool MORE>
+                        "v_alignbit_b32 %[ws], %[ws], %[q], 31"
+    template <int P, bool FIRST>
     __device__ static __forceinline__ void edge_in(float &q, unsigned idx_old, float a, float b, unsigned &ws, float &m1,
-                                                   float &m2, unsigned &sq, float inf) {
+                                                   float &m2, float inf) {
         float t;
-        static_assert(!FIRST || MORE, "a check has at least two edges");
         if constexpr (FIRST)
-            asm(LDPC_EDGE_OLD LDPC_EDGE_STEP LDPC_EDGE_BOOK1
-                : [q] "+v"(q), [t] "=&v"(t), [ws] "+v"(ws), [m1] "=&v"(m1), [m2] "=&v"(m2), [sq] "=v"(sq)
+            asm(LDPC_EDGE_OLD LDPC_EDGE_BOOK1
+                : [q] "+v"(q), [t] "=&v"(t), [ws] "+v"(ws), [m1] "=&v"(m1), [m2] "=&v"(m2)
                 : [p] "i"(P), [idx] "v"(idx_old), [a] "v"(a), [b] "v"(b), [S] "s"(0x80000000u), [inf] "v"(inf) : "vcc");
-        else if constexpr (MORE)
-            asm(LDPC_EDGE_OLD LDPC_EDGE_STEP LDPC_EDGE_BOOK
-                : [q] "+v"(q), [t] "=&v"(t), [ws] "+v"(ws), [m1] "+v"(m1), [m2] "+v"(m2), [sq] "+v"(sq)
-                : [p] "i"(P), [idx] "v"(idx_old), [a] "v"(a), [b] "v"(b), [S] "s"(0x80000000u) : "vcc");
         else
             asm(LDPC_EDGE_OLD LDPC_EDGE_BOOK
-                : [q] "+v"(q), [t] "=&v"(t), [m1] "+v"(m1), [m2] "+v"(m2), [sq] "+v"(sq)
-                : [p] "i"(P), [idx] "v"(idx_old), [a] "v"(a), [b] "v"(b), [ws] "v"(ws), [S] "s"(0x80000000u) : "vcc");
+                : [q] "+v"(q), [t] "=&v"(t), [ws] "+v"(ws), [m1] "+v"(m1), [m2] "+v"(m2)
+                : [p] "i"(P), [idx] "v"(idx_old), [a] "v"(a), [b] "v"(b), [S] "s"(0x80000000u) : "vcc");
     }
     // the same for an edge whose input q is given (no previous message to take off)
-    template <bool FIRST, bool MORE>
-    __device__ static __forceinline__ void edge_in_given(float q, unsigned &ws, float &m1, float &m2, unsigned &sq, float inf) {
-        if constexpr (MORE) asm("v_add_u32 %0, %0, %0" : "+v"(ws));
+    template <bool FIRST>
+    __device__ static __forceinline__ void edge_in_given(float q, unsigned &ws, float &m1, float &m2, float inf) {
         if constexpr (FIRST)
-            asm(LDPC_EDGE_BOOK1 : [m1] "=&v"(m1), [m2] "=&v"(m2), [sq] "=v"(sq) : [q] "v"(q), [inf] "v"(inf));
+            asm(LDPC_EDGE_BOOK1 : [m1] "=&v"(m1), [m2] "=&v"(m2), [ws] "+v"(ws) : [q] "v"(q), [inf] "v"(inf));
         else
-            asm(LDPC_EDGE_BOOK : [m1] "+v"(m1), [m2] "+v"(m2), [sq] "+v"(sq) : [q] "v"(q));
+            asm(LDPC_EDGE_BOOK : [m1] "+v"(m1), [m2] "+v"(m2), [ws] "+v"(ws) : [q] "v"(q));
     }
 #undef LDPC_EDGE_OLD
-#undef LDPC_EDGE_STEP
 #undef LDPC_EDGE_BOOK
 #undef LDPC_EDGE_BOOK1
 };
@@ -123,19 +117,18 @@ template <> struct SNum<double> {
             : "vcc");
         return __hiloint2double(hi, lo);
     }
-    template <int P, bool FIRST, bool MORE>
+    template <int P, bool FIRST>
     __device__ static __forceinline__ void edge_in(double &q, unsigned idx_old, double a, double b, unsigned &ws, double &m1,
-                                                   double &m2, unsigned &sq, double inf) {
+                                                   double &m2, double inf) {
         q = q - with_sign((int)idx_old == P ? b : a, ws);
-        edge_in_given<FIRST, MORE>(q, ws, m1, m2, sq, inf);
+        edge_in_given<FIRST>(q, ws, m1, m2, inf);
     }
-    template <bool FIRST, bool MORE>
-    __device__ static __forceinline__ void edge_in_given(double q, unsigned &ws, double &m1, double &m2, unsigned &sq, double inf) {
-        if constexpr (MORE) asm("v_add_u32 %0, %0, %0" : "+v"(ws));  // the compiler would turn `ws += ws` into a shift
-        if constexpr (FIRST) { m1 = inf; m2 = inf; sq = 0; }
+    template <bool FIRST>
+    __device__ static __forceinline__ void edge_in_given(double q, unsigned &ws, double &m1, double &m2, double inf) {
+        if constexpr (FIRST) { m1 = inf; m2 = inf; }
         m2 = second(m1, m2, q);
         m1 = min_abs(m1, q);
-        sq = (sq << 1) | (sign_word(q) >> 31);
+        ws = __builtin_amdgcn_alignbit(ws, sign_word(q), 31);  // old sign out at the top, new sign in at the bottom
     }
     __device__ static __forceinline__ double pick_add(double q, double m1, double a, double b, unsigned &bits) {
         const double mag = pick_min(q, m1, a, b, bits);
