@@ -34,7 +34,8 @@ UNITS += [("decode_spec_spa.o", "decode_spec_spa.hip", []),
           ("decode_spec_r1w_r0.o", "decode_spec_r1w.hip", ["-DLDPC_R1W_RULE=0"]),
           ("decode_spec_r1w_r6.o", "decode_spec_r1w.hip", ["-DLDPC_R1W_RULE=6"]),
           ("decode_spec.o", "decode_spec.hip", []),
-          ("decode_spec_h.o", "decode_spec_h.hip", [])]
+          ("decode_spec_h.o", "decode_spec_h.hip", []),
+          ("decode_lnms_h.o", "decode_lnms_h.hip", [])]
 UNITS += [(f"decode_qc_r{k}.o", "decode_qc.hip", [f"-DLDPC_QC_RULE={k}"]) for k in (1, 2, 3, 4, 6)]
 UNITS += [("decode_qc_r0.o", "decode_qc_r0.hip", []),
           ("decode_qc_lnms.o", "decode_qc_lnms.hip", []),
@@ -45,15 +46,15 @@ UNITS += [("decode_qc_r0.o", "decode_qc_r0.hip", []),
           ("bitflip.o", "bitflip.hip", []),
           ("encode_qc.o", "encode_qc.hip", []),
           ("rate_match.o", "rate_match.hip", [])]
-HEADERS = ["bp_common.h", "extra_kernels.h", "sweep_fused.h", "bp_math.h", "spec_common.h", "spec_r1w_plan.h", os.path.join("gen", "codes_gen.h"),
+HEADERS = ["bp_common.h", "extra_kernels.h", "sweep_fused.h", "bp_math.h", "spec_common.h", "spec_r1w_plan.h", "lnms_plan.h", "half2_ops.h", os.path.join("gen", "codes_gen.h"),
            os.path.join(ROOT, "include", "ldpc_amd.h")]
 
 
 #: source files each kernel family is built from (for stamping counter profiles)
-KERNEL_SOURCES = {"spec_lnms": ["decode_lnms.hip"], "spec_r0w": ["decode_spec_r1w.hip", "spec_r1w_plan.h"],
+KERNEL_SOURCES = {"spec_lnms_f16x2": ["decode_lnms_h.hip", "lnms_plan.h", "half2_ops.h"], "spec_lnms": ["decode_lnms.hip", "lnms_plan.h"], "spec_r0w": ["decode_spec_r1w.hip", "spec_r1w_plan.h"],
                   "spec_r1w": ["decode_spec_r1w.hip", "spec_r1w_plan.h"], "spec_spaw": ["decode_spec_spaw.hip", "spec_r1w_plan.h"],
                   "spec_spa": ["decode_spec_spa.hip"], "spec_r0": ["decode_spec.hip"], "spec_r1": ["decode_spec.hip"],
-                  "spec_oms": ["decode_spec.hip"], "spec_r1_f16x2": ["decode_spec_h.hip"], "spec_omsw": ["decode_spec_r1w.hip", "spec_r1w_plan.h"], "qc_lnms": ["decode_qc_lnms.hip"], "qc_r0": ["decode_qc_r0.hip"],
+                  "spec_oms": ["decode_spec.hip"], "spec_r1_f16x2": ["decode_spec_h.hip", "half2_ops.h"], "spec_omsw": ["decode_spec_r1w.hip", "spec_r1w_plan.h"], "qc_lnms": ["decode_qc_lnms.hip"], "qc_r0": ["decode_qc_r0.hip"],
                   "qc": ["decode_qc.hip"], "csr": ["decode_csr.hip"]}
 
 

@@ -1,0 +1,482 @@
+// Row-layered normalised min-sum in packed half precision, TWO frames per lane (LDPC_RULE_LNMS with
+// compute_dtype LDPC_F16): the reduced-precision fast mode of decode_lnms.hip.  Neither the rule nor
+// the arithmetic has a counterpart in the reference (flooding schedules in float64 only); the mode is
+// bit-exact with nothing and is validated statistically against the float32 kernel on the same
+// frames (tests/test_gpu_half_lnms.py).
+//
+// Organisation as in decode_lnms.hip: thread (f, z) owns check (br, z) of every block row of slot f,
+// posteriors of the shared block columns in LDS, channel values of the degree-one columns re-read
+// from the LLR array, compressed check state in registers / LDS.  A slot holds a PAIR of frames:
+// every 32-bit word carries the two frames' half-precision numbers (or 16-bit state fields) side by
+// side and every packed instruction works on both, so the address arithmetic, the LDS accesses and
+// the loop overhead of a layer are paid once per pair.
+//
+// Packed instructions have no compare or select.  Both selects of the rule are done on the bit
+// patterns instead: with e = 1 where a 16-bit difference is zero (one saturating subtraction) the
+// magnitude is A + e (B - A) in INTEGER arithmetic (v_pk_mad_u16), exact for positive half-precision
+// patterns.  Check state of one pair:
+//   A, B   scale * smallest / second smallest input magnitude, clamped to 2000
+//   W      per frame 16 bits: bit 15 sign parity of the inputs | bit 14 hard decision of the check's
+//          degree-one variable | bits 13-10 position of the smallest input | bits 9-0 input signs
+//          (first edge highest).  Checks of more than ten inputs keep a second word for the signs of
+//          inputs 10... and use five position bits.
+// Hard decisions are the sign bits of the posteriors (a posterior of exactly +0 decides 0 here).
+// A frame of a pair that converges is written out at once; its partner goes on.
+#include <cstdio>
+#include <cstdlib>
+
+#include "spec_common.h"
+#include "lnms_plan.h"
+#include "half2_ops.h"
+#include "extra_kernels.h"
+
+namespace ldpc {
+
+constexpr int kShortRow = 10;  // inputs whose signs fit the first state word
+
+template <class C>
+struct LnHPlan {
+    typedef LnPlan<C> PL;
+    static constexpr bool is_long(int br) { return PL::rdeg(br) > kShortRow; }
+    static constexpr int da(int br) { return is_long(br) ? kShortRow : PL::rdeg(br); }
+    static constexpr int words(int br) { return is_long(br) ? 4 : 3; }
+    static constexpr bool supported() { return PL::supported() && C::MAX_DC <= 2 * kShortRow; }
+    // registers taken by the state of block rows [0, rl)
+    static constexpr int regs(int rl)
+    {
+        int c = 0;
+        for (int r = 0; r < rl && r < C::MB; ++r) c += words(r);
+        return c;
+    }
+    // block rows [rl, MB) keep their state in LDS as three words: none of them may be long
+    static constexpr bool spill_ok(int rl)
+    {
+        for (int r = rl; r < C::MB; ++r) if (is_long(r)) return false;
+        return true;
+    }
+};
+
+template <class C, int F, int RL, int WPE>
+__global__ void __launch_bounds__((LnLayout<C, float, F, RL>::THREADS)) __attribute__((amdgpu_waves_per_eu(WPE, 8)))
+lnms_h_kernel(int max_iters, int early_exit, float scale_f, const float *__restrict__ llr, long long frames,
+              uint8_t *__restrict__ hard_out, int *__restrict__ iters_out, uint8_t *__restrict__ conv_out)
+{
+    typedef LnPlan<C> PL;
+    typedef LnHPlan<C> HP;
+    typedef LnLayout<C, float, F, RL> LY;  // a pair's word has the size of a float: same layout
+    static_assert(HP::supported() && HP::spill_ok(RL), "code shape not supported by the packed layered kernel");
+    static_assert(F <= 8, "the per-frame syndrome flags are one row of sixteen");
+    constexpr int Z = C::Z, NB = C::NB, MB = C::MB;
+    constexpr int n = NB * Z;
+    extern __shared__ __align__(16) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const bool lane_on = tid < F * Z;
+    const int f = (F == 1 || !lane_on) ? 0 : tid / Z;
+    const int z = lane_on ? tid - f * Z : 0;
+    const unsigned zb = (unsigned)z * 4;
+    const unsigned zbP = (unsigned)f * LY::SLOT_BYTES + zb;  // absolute LDS addresses from here on
+    const unsigned zbPW = zbP + LY::VEC;
+    const unsigned stA = zbP;                                // spilled check state of this thread: A, B, W
+    int *slot_bad = reinterpret_cast<int *>(smem + LY::FLAG_OFF);  // [2 f + h]: frame h of slot f failed the test
+    volatile int *slot_bad_now = slot_bad;                   // polled while other waves may still be writing
+    const unsigned long long slot_mask = (Z >= 64 ? ~0ull : ((1ull << (Z & 63)) - 1ull)) << ((f * Z) & 63);
+    unsigned long long wave_slot_mask = slot_mask;           // lanes of this wave on the same slot as this lane
+    if constexpr (!LY::SINGLE && F > 1) {
+        static_for<0, F>([&](auto ff) {
+            const unsigned long long m = __ballot(lane_on && f == ff);
+            if (f == ff) wave_slot_mask = m;
+        });
+    } else if constexpr (!LY::SINGLE) {
+        wave_slot_mask = ~0ull;
+    }
+    const h2 scale2 = pack_half2(scale_f, scale_f);
+
+    const long long pairs = (frames + 1) / 2, groups = (pairs + F - 1) / F;
+    for (long long grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+        const long long fr0 = (F == 1 ? grp : grp * F + f) * 2, fr1 = fr0 + 1;
+        const bool act0 = lane_on && fr0 < frames, act1 = lane_on && fr1 < frames;
+        // loads never depend on the flags: a lane without a frame reads the group's first frame,
+        // which exists.  One scalar base address per group, 32-bit offsets per lane.
+        const float *lf = llr + grp * (2 * F) * n;
+        const unsigned o0 = (fr0 < frames ? (unsigned)(2 * f) : 0u) * (unsigned)n + (unsigned)z;
+        const unsigned o1 = (fr1 < frames ? (unsigned)(2 * f + 1) : 0u) * (unsigned)n + (unsigned)z;
+        auto load_pair = [&](unsigned off) -> h2 { return pack_half2(lf[o0 + off], lf[o1 + off]); };
+
+        h2 A[RL > 0 ? RL : 1], B[RL > 0 ? RL : 1];
+        unsigned W[RL > 0 ? RL : 1], WX[RL > 0 ? RL : 1];
+        static_for<0, MB>([&](auto br) {
+            if constexpr (br < RL) { A[br] = 0u; B[br] = 0u; W[br] = 0u; WX[br] = 0u; }
+            else if (lane_on) {
+                lds_put<unsigned>(stA + LY::state_off(br - RL), 0u);
+                lds_put<unsigned>(stA + LY::state_off(br - RL) + Z * 4, 0u);
+                lds_put<unsigned>(stA + LY::state_off(br - RL) + 2 * Z * 4, 0u);
+            }
+        });
+        static_for<0, NB>([&](auto bc) {
+            if constexpr (PL::shared(bc)) {
+                const h2 l = load_pair(bc * Z);
+                if (lane_on) lds_put<h2>(ln_addr<LY, PL::lds_index(bc), 0>(zb, zbP, zbPW), l);  // idle lanes alias lane 0
+            }
+        });
+        if constexpr (!LY::SINGLE) {
+            if (tid < 2 * F) slot_bad[tid] = 0;
+            __syncthreads();
+        }
+
+        // wx: the second state word of a long row, and the word that holds bit 14 (the hard decision
+        // of the row's degree-one variable) in either case
+        auto load_state = [&](auto br, h2 &a, h2 &b, unsigned &w, unsigned &wx) {
+            if constexpr (br < RL) { a = A[br]; b = B[br]; w = W[br]; wx = HP::is_long(br) ? WX[br] : w; }
+            else {
+                a = lds_get<h2>(stA + LY::state_off(br - RL));
+                b = lds_get<h2>(stA + LY::state_off(br - RL) + Z * 4);
+                w = lds_get<unsigned>(stA + LY::state_off(br - RL) + 2 * Z * 4);
+                wx = w;
+            }
+        };
+        auto load_bits_word = [&](auto br) -> unsigned {
+            if constexpr (br < RL) return HP::is_long(br) ? WX[br] : W[br];
+            else return lds_get<unsigned>(stA + LY::state_off(br - RL) + 2 * Z * 4);
+        };
+        // index inside the frame, and the pair's channel values, of the degree-one variable of block row br
+        auto priv_index = [&](auto br) -> int {
+            constexpr int e = C::row_ptr[br] + PL::priv_pos(br), bc = C::row_col[e], s = C::row_shift[e];
+            int zo = z;
+            asm volatile("" : "+v"(zo));  // one address per block row, computed where it is used
+            if constexpr (s == 0) return bc * Z + zo;
+            else { const int v = zo + s; return bc * Z + (v >= Z ? v - Z : v); }
+        };
+        auto load_priv = [&](auto br) -> h2 {
+            constexpr int e = C::row_ptr[br] + PL::priv_pos(br), bc = C::row_col[e], s = C::row_shift[e];
+            unsigned o = 0;
+            asm volatile("" : "+v"(o));  // one address per block row, computed where it is used
+            if constexpr (s != 0) o += (unsigned)z + s >= (unsigned)Z ? (unsigned)(s - Z) : (unsigned)s;
+            return load_pair(o + (unsigned)(bc * Z));
+        };
+        // Bit 14 of a row's state holds the hard decisions of its degree-one variable whenever a
+        // syndrome test may follow; before the first sweep they are the channel's.
+        if (early_exit) {
+            static_for<0, MB>([&](auto br) {
+                if constexpr (PL::is_priv_layer(br)) {
+                    const unsigned hb = (load_priv(br) >> 1) & 0x40004000u;
+                    if constexpr (br < RL) { if constexpr (HP::is_long(br)) WX[br] = hb; else W[br] = hb; }
+                    else if (lane_on) lds_put<unsigned>(stA + LY::state_off(br - RL) + 2 * Z * 4, hb);
+                }
+            });
+        }
+        // hard decisions, iteration count and flag of frame h (0 / 1) of the pair
+        auto write_half = [&](int h, long long frame, int iters, int conv) {
+            const int sh = 15 + 16 * h;
+            static_for<0, NB>([&](auto bc) {
+                if constexpr (PL::cdeg(bc) != 1) {
+                    h2 v;
+                    if constexpr (PL::shared(bc)) v = lds_get<h2>(ln_addr<LY, PL::lds_index(bc), 0>(zb, zbP, zbPW));
+                    else v = load_pair(bc * Z);  // in no check at all: the channel decides
+                    hard_out[frame * n + bc * Z + z] = (uint8_t)((v >> sh) & 1u);
+                }
+            });
+            static_for<0, MB>([&](auto br) {
+                if constexpr (PL::priv_pos(br) >= 0) {
+                    unsigned hb;
+                    if constexpr (PL::rdeg(br) >= 2) hb = (load_bits_word(br) >> (sh - 1)) & 1u;
+                    else hb = (load_priv(br) >> sh) & 1u;
+                    hard_out[frame * n + priv_index(br)] = (uint8_t)hb;
+                }
+            });
+            if (z == 0) { iters_out[frame] = iters; conv_out[frame] = (uint8_t)conv; }
+        };
+
+        constexpr int NPL = PL::n_priv_layers();
+        constexpr int SYN_FIRST = 2, SYN_EVERY = 6;  // block rows between looks at the outcome of the syndrome test
+        h2 lp_next = 0u;  // channel values of the next layer's degree-one variable, requested one layer ahead
+        if constexpr (NPL > 0) lp_next = load_priv(IC<PL::priv_layer(0)>{});
+
+        bool done0 = !act0, done1 = !act1;
+        int res_conv0 = 0, res_conv1 = 0;
+        for (int t = 0;; ++t) {
+            const bool last = t == max_iters;
+            if (early_exit || last) {
+                // ---- syndromes of the two frames: parities of the posteriors' sign bits
+                if constexpr (!LY::SINGLE) __syncthreads();
+                if (last && early_exit) break;  // no test after the last sweep
+                const bool slot_done = done0 && done1;
+                unsigned bad = 0;   // bit 15 / bit 31: a check of this lane fails in frame 0 / 1
+                bool skip = false;  // the same in all lanes of a wave
+                if (!slot_done || !LY::SINGLE) {
+                    static_for<0, MB>([&](auto br) {
+                        if constexpr (br == SYN_FIRST || (br > SYN_FIRST && (br - SYN_FIRST) % SYN_EVERY == 0)) {
+                            // a failed test needs no more rows
+                            const bool b0 = (bad & 0x8000u) != 0 && !done0, b1 = (bad & 0x80000000u) != 0 && !done1;
+                            bool known0 = done0 || (__ballot(b0) & wave_slot_mask) != 0ull;
+                            bool known1 = done1 || (__ballot(b1) & wave_slot_mask) != 0ull;
+                            if constexpr (!LY::SINGLE) {
+                                if (b0) slot_bad_now[2 * f] = 1;
+                                if (b1) slot_bad_now[2 * f + 1] = 1;
+                                known0 = known0 || slot_bad_now[2 * f] != 0;
+                                known1 = known1 || slot_bad_now[2 * f + 1] != 0;
+                            }
+                            skip = __ballot(!(known0 && known1)) == 0ull;
+                        }
+                        if (skip || slot_done) return;
+                        constexpr int e0 = C::row_ptr[br], D = C::row_ptr[br + 1] - e0, PP = PL::priv_pos(br);
+                        unsigned zl = zb;
+                        asm volatile("" : "+v"(zl));  // keep the rotated addresses out of loop-invariant hoisting
+                        h2 v[D > 0 ? D : 1];
+                        static_for<0, D>([&](auto p) {  // all reads of the row first, then their signs
+                            if constexpr (p != PP) {
+                                constexpr int bc = C::row_col[e0 + p], s = C::row_shift[e0 + p];
+                                v[p] = lds_get<h2>(ln_addr<LY, PL::lds_index(bc), s>(zl, zbP, zbPW));
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        });
+                        unsigned par = 0;
+                        static_for<0, D>([&](auto p) {
+                            if constexpr (p != PP) par ^= v[p];
+                            else if constexpr (D >= 2) par ^= load_bits_word(br) << 1;
+                            else par ^= load_priv(br);  // a check of degree one
+                        });
+                        bad |= par;
+                    });
+                }
+                const bool bad0 = (bad & 0x8000u) != 0 && !done0, bad1 = (bad & 0x80000000u) != 0 && !done1;
+                bool ok0, ok1, any_bad = false;
+                if constexpr (LY::SINGLE) {
+                    ok0 = (__ballot(bad0) & slot_mask) == 0ull;
+                    ok1 = (__ballot(bad1) & slot_mask) == 0ull;
+                } else {
+                    if (bad0) slot_bad[2 * f] = 1;
+                    if (bad1) slot_bad[2 * f + 1] = 1;
+                    __syncthreads();
+                    ok0 = slot_bad[2 * f] == 0;
+                    ok1 = slot_bad[2 * f + 1] == 0;
+                    static_for<0, 2 * F>([&](auto k) { any_bad |= slot_bad[k] != 0; });
+                }
+                if (last) {
+                    res_conv0 = ok0 ? 1 : 0;
+                    res_conv1 = ok1 ? 1 : 0;
+                    break;
+                }
+                if (!done0 && ok0) { write_half(0, fr0, t, 1); done0 = true; }
+                if (!done1 && ok1) { write_half(1, fr1, t, 1); done1 = true; }
+                if constexpr (LY::SINGLE) {
+                    if (__ballot(!(done0 && done1)) == 0ull) break;
+                } else {
+                    if (!any_bad) break;  // every frame that was still running has just converged
+                    __syncthreads();
+                    if (tid < 2 * F) slot_bad[tid] = 0;
+                }
+            }
+            // ---- one sweep over the layers
+            const bool want_bits = early_exit || t == max_iters - 1;
+            const bool slot_done = done0 && done1;
+            static_for<0, MB>([&](auto br) {
+                constexpr int e0 = C::row_ptr[br], D = C::row_ptr[br + 1] - e0, PP = PL::priv_pos(br);
+                constexpr bool LONG = HP::is_long(br);
+                constexpr int DA = HP::da(br), DB = D - DA;
+                if constexpr (D >= 2) {
+                    if constexpr (!LY::SINGLE && PL::barrier_before(br)) __syncthreads();
+                    h2 lp = 0u;
+                    if constexpr (PP >= 0) {
+                        constexpr int j = PL::priv_layer_ord(br);
+                        lp = lp_next;
+                        if constexpr (NPL > 1) lp_next = load_priv(IC<PL::priv_layer((j + 1) % NPL)>{});
+                    }
+                    if (!slot_done) {
+                        h2 q[D];
+                        unsigned off[D];
+                        h2 Ao, Bo;
+                        unsigned w, wx;
+                        load_state(br, Ao, Bo, w, wx);
+                        unsigned zl = zb;
+                        asm volatile("" : "+v"(zl));  // hundreds of hoisted addresses would spill
+                        // all posteriors of the row are requested first: one LDS round trip per row
+                        static_for<0, D>([&](auto p) {
+                            if constexpr (p == PP) {
+                                off[p] = 0;
+                            } else {
+                                constexpr int bc = C::row_col[e0 + p], s = C::row_shift[e0 + p];
+                                off[p] = ln_addr<LY, PL::lds_index(bc), s>(zl, zbP, zbPW);
+                                q[p] = lds_get<h2>(off[p]);
+                                __builtin_amdgcn_sched_barrier(0);  // address, read, address, read
+                            }
+                        });
+                        const unsigned idx2 = pk_shr<10>(w) & (LONG ? 0x001f001fu : 0x000f000fu);
+                        const unsigned dba_o = pk_sub_u16(Bo, Ao);
+                        // bit 15 of a half of wsa / wsb: sign of the old message on the current edge.  Every edge
+                        // shifts it out and the sign of its input in at the bottom: the words end as the new signs.
+                        unsigned wsa = pk_shl<16 - DA>(w ^ pk_sign_fill(w));
+                        unsigned wsb = 0;
+                        if constexpr (LONG) wsb = pk_shl<16 - DB>(wx ^ pk_sign_fill(wx));
+                        h2 m1 = kHalfMax2, m2 = kHalfMax2;
+                        unsigned sx = 0;  // sign parity of the inputs (bits 15 and 31)
+                        static_for<0, D>([&](auto p) {
+                            unsigned &ws = (p < DA) ? wsa : wsb;
+                            if constexpr (p == PP) {
+                                q[p] = lp;  // a variable of degree one always sends its channel value
+                            } else {
+                                // the edge's old message: magnitude B if it held the minimum last time, else A
+                                unsigned d = idx2;
+                                if constexpr (p != 0) d ^= (unsigned)p * 0x00010001u;
+                                const unsigned mag = pk_mad_u16(pk_is_zero(d), dba_o, Ao);
+                                q[p] = pk_sub(q[p], and_or(ws, kSignMask, mag));
+                            }
+                            const h2 a = q[p] & kAbsMask;
+                            m2 = pk_min(m2, pk_max(m1, a));
+                            m1 = pk_min(m1, a);
+                            ws = pk_funnel(ws, pk_shr<15>(q[p]));
+                            sx ^= q[p];
+                        });
+                        const unsigned px = sx & kSignMask;
+                        const h2 An = pk_min(pk_mul(m1, scale2), kHalfClamp2), Bn = pk_min(pk_mul(m2, scale2), kHalfClamp2);
+                        const unsigned Anp = An | px;  // the parity of the inputs folded into the new messages
+                        const unsigned dba_n = pk_sub_u16(Bn, An);
+                        unsigned mina = 0, minb = 0;   // per edge: does it hold the smallest magnitude?
+                        unsigned privbit = 0;
+                        static_for<0, D>([&](auto p) {
+                            unsigned &mn = (p < DA) ? mina : minb;
+                            const unsigned e = pk_is_zero((q[p] & kAbsMask) ^ m1);
+                            const unsigned magp = pk_mad_u16(e, dba_n, Anp);
+                            mn = pk_funnel(mn, e);
+                            const h2 pn = pk_add(q[p], and_xor(q[p], magp, kSignMask));  // the variable's new posterior
+                            if constexpr (p != PP) {
+                                lds_put<h2>(off[p], pn);
+                                __builtin_amdgcn_sched_barrier(0);  // block, write, block, write
+                            } else if (want_bits) {
+                                privbit = (pn >> 1) & 0x40004000u;
+                            }
+                        });
+                        // position of the first smallest input, per frame: edge p sits at bit D - 1 - p
+                        unsigned c0, c1;
+                        if constexpr (LONG) {
+                            c0 = ((mina & 0xffffu) << DB) | (minb & 0xffffu);
+                            c1 = ((mina >> 16) << DB) | (minb >> 16);
+                        } else {
+                            c0 = mina & 0xffffu;
+                            c1 = mina >> 16;
+                        }
+                        const unsigned i0 = (unsigned)__builtin_clz(c0 | 1u) - (unsigned)(32 - D);
+                        const unsigned i1 = (unsigned)__builtin_clz(c1 | 1u) - (unsigned)(32 - D);
+                        unsigned wn = wsa | px | (i0 << 10) | (i1 << 26);
+                        unsigned wxn = 0;
+                        if constexpr (LONG) wxn = wsb | px | privbit;
+                        else wn |= privbit;
+                        if constexpr (br < RL) {
+                            A[br] = An; B[br] = Bn; W[br] = wn;
+                            if constexpr (LONG) WX[br] = wxn;
+                        } else {
+                            lds_put<h2>(stA + LY::state_off(br - RL), An);
+                            lds_put<h2>(stA + LY::state_off(br - RL) + Z * 4, Bn);
+                            lds_put<unsigned>(stA + LY::state_off(br - RL) + 2 * Z * 4, wn);
+                        }
+                    }
+                }
+            });
+        }
+        // frames that never passed a test (or fixed work: every frame)
+        const int res_iters = early_exit ? max_iters - 1 : max_iters;
+        if (act0 && !done0) write_half(0, fr0, res_iters, res_conv0);
+        if (act1 && !done1) write_half(1, fr1, res_iters, res_conv1);
+        if constexpr (!LY::SINGLE) __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------ host
+// How many block rows keep their state in registers: planned like the float kernel (a workgroup of
+// four or more waves is the only one on its compute unit, smaller ones run three waves per SIMD),
+// with about 53 registers left for everything that is not check state.
+template <class C, int F>
+struct LnHConfig {
+    typedef LnHPlan<C> HP;
+    static constexpr int WAVES = ((F * C::Z + 63) / 64);
+    static constexpr int WPE = WAVES >= 4 ? (WAVES + 3) / 4 : 3;
+    static constexpr int VGPRS = WPE <= 2 ? 256 : (512 / WPE) / 8 * 8;
+    static constexpr int STATE_REGS = VGPRS - 53 > 180 ? 180 : VGPRS - 53;
+    static constexpr int rl()
+    {
+        int r = 0;
+        while (r < C::MB && HP::regs(r + 1) <= STATE_REGS) ++r;
+        return r;
+    }
+    static constexpr int RL = rl();
+    static constexpr bool OK = HP::supported() && HP::spill_ok(RL) && WPE <= 4 && F <= 8 &&
+                               LnLayout<C, float, F, RL>::LDS_BYTES <= 160 * 1024;
+};
+// Slots per workgroup: the packaged default, doubled when that makes the number of waves a multiple
+// of the four SIMDs (see decode_lnms.hip).
+template <class C, int F>
+struct LnHSlots {
+    static constexpr int W1 = (F * C::Z + 63) / 64, W2 = (2 * F * C::Z + 63) / 64;
+    static constexpr bool DOUBLE = W1 >= 4 && W1 % 4 != 0 && W2 % 4 == 0 && LnHConfig<C, 2 * F>::OK;
+    static constexpr int value = DOUBLE ? 2 * F : F;
+};
+
+template <class C, int F>
+static hipError_t launch_lnms_h(const ldpc_decode_config &cfg, const Launch &io, int num_cus, const char **name)
+{
+    typedef LnHConfig<C, F> CF;
+    typedef LnLayout<C, float, F, CF::RL> LY;
+    auto k = lnms_h_kernel<C, F, CF::RL, CF::WPE>;
+    static int static_lds = -1;  // the kernel addresses LDS from 0: it must own the whole segment
+    if (static_lds < 0) {
+        hipFuncAttributes attr;
+        hipError_t ea = hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(k));
+        if (ea != hipSuccess) return ea;
+        static_lds = (int)attr.sharedSizeBytes;
+    }
+    if (static_lds != 0) return hipErrorInvalidConfiguration;
+    int per_cu = 0;
+    hipError_t e = kernel_setup(reinterpret_cast<const void *>(k), LY::THREADS, LY::LDS_BYTES, &per_cu);
+    if (e != hipSuccess) return e;
+    if (per_cu < 1) per_cu = 1;
+    if (getenv("LDPC_DEBUG_OCCUPANCY"))
+        fprintf(stderr, "lnms_h_kernel<%s>: %d frame pairs per workgroup, %d block rows in registers, "
+                "%d workgroups of %d threads per CU, %d B LDS each\n",
+                C::name, F, CF::RL, per_cu, LY::THREADS, LY::LDS_BYTES);
+    const long long pairs = (io.frames + 1) / 2, groups = (pairs + F - 1) / F;
+    long long grid = (long long)num_cus * (long long)per_cu * 2;
+    if (grid > groups) grid = groups;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(LY::THREADS), LY::LDS_BYTES, io.stream, cfg.max_iters,
+                       cfg.early_exit, (float)cfg.scale, reinterpret_cast<const float *>(io.llr), io.frames,
+                       io.hard, io.iters, io.converged);
+    *name = "spec_lnms_f16x2";
+    return hipGetLastError();
+}
+
+// Layered min-sum in packed half precision on the compiled-in codes: float LLRs, no posteriors out.
+hipError_t launch_spec_lnms_half(int spec_id, const ldpc_decode_config &cfg, const Launch &io, int num_cus,
+                                 const char **name, bool *supported)
+{
+    *supported = false;
+    if (cfg.rule != LDPC_RULE_LNMS || io.llr_dtype != LDPC_F32 || io.posterior) return hipSuccess;
+    int id = 0;
+#define LDPC_LAUNCH(CODE, SLOTS)                                                                   \
+    if (spec_id == id) {                                                                           \
+        if constexpr (LnHPlan<CODE>::supported()) {                                                \
+            constexpr int FS = LnHSlots<CODE, SLOTS>::value;                                       \
+            if constexpr (LnHConfig<CODE, FS>::OK) {                                               \
+                *supported = true;                                                                 \
+                return launch_lnms_h<CODE, FS>(cfg, io, num_cus, name);                            \
+            }                                                                                      \
+        }                                                                                          \
+        return hipSuccess;                                                                         \
+    }                                                                                              \
+    ++id;
+#ifdef LDPC_LNMS_DEV_ONLY  // development aid: instantiate one code only
+    (void)id;
+    if constexpr (LnHPlan<LDPC_LNMS_DEV_ONLY>::supported()) {
+        constexpr int FS = LnHSlots<LDPC_LNMS_DEV_ONLY, 1>::value;
+        if constexpr (LnHConfig<LDPC_LNMS_DEV_ONLY, FS>::OK) {
+            *supported = true;
+            return launch_lnms_h<LDPC_LNMS_DEV_ONLY, FS>(cfg, io, num_cus, name);
+        }
+    }
+#else
+    LDPC_FOR_EACH_SPEC_CODE(LDPC_LAUNCH)
+#endif
+#undef LDPC_LAUNCH
+    return hipSuccess;
+}
+
+}  // namespace ldpc

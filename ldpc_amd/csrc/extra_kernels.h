@@ -5,6 +5,10 @@
 
 namespace ldpc {
 
+// decode_lnms_h.hip: layered min-sum in packed half precision, two frames per lane (compute_dtype LDPC_F16)
+hipError_t launch_spec_lnms_half(int spec_id, const ldpc_decode_config &cfg, const Launch &io, int num_cus,
+                                 const char **kernel_name, bool *supported);
+
 // bitflip.hip: ldpc.py:82-135
 hipError_t launch_bitflip(const CsrDev &code, int max_iters, int num_active_checks, const Launch &io, int num_cus,
                           const char **kernel_name, bool *supported);

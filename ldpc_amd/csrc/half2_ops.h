@@ -43,4 +43,53 @@ __device__ __forceinline__ bool half_positive(h2 v, int h)
     return h ? (int)v > 0xffff : ((int)(v << 16) > 0);
 }
 
+// Packed 16-bit integer helpers (both halves at once).  Inline constants of packed instructions are
+// read from the low half by both lanes (op_sel_hi 0 for that operand).
+// 1 - x, saturating at 0: 1 where x == 0, else 0
+__device__ __forceinline__ unsigned pk_is_zero(unsigned x)
+{
+    unsigned d; asm("v_pk_sub_u16 %0, 1, %1 op_sel_hi:[0,1] clamp" : "=v"(d) : "v"(x)); return d;
+}
+__device__ __forceinline__ unsigned pk_mad_u16(unsigned a, unsigned b, unsigned c)
+{
+    unsigned d; asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d;
+}
+// 2 w + s: a funnel shift by one bit per half when s is 0 or 1
+__device__ __forceinline__ unsigned pk_funnel(unsigned w, unsigned s)
+{
+    unsigned d; asm("v_pk_mad_u16 %0, %1, 2, %2 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(w), "v"(s)); return d;
+}
+__device__ __forceinline__ unsigned pk_sub_u16(unsigned a, unsigned b)
+{
+    unsigned d; asm("v_pk_sub_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d;
+}
+template <int N>
+__device__ __forceinline__ unsigned pk_shl(unsigned x)
+{
+    static_assert(N >= 0 && N < 16, "shift of a 16-bit half");
+    if constexpr (N == 0) return x;
+    else { unsigned d; asm("v_pk_lshlrev_b16 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(d) : "n"(N), "v"(x)); return d; }
+}
+template <int N>
+__device__ __forceinline__ unsigned pk_shr(unsigned x)
+{
+    static_assert(N >= 0 && N < 16, "shift of a 16-bit half");
+    if constexpr (N == 0) return x;
+    else { unsigned d; asm("v_pk_lshrrev_b16 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(d) : "n"(N), "v"(x)); return d; }
+}
+// the top bit of each half spread over the half
+__device__ __forceinline__ unsigned pk_sign_fill(unsigned x)
+{
+    unsigned d; asm("v_pk_ashrrev_i16 %0, 15, %1 op_sel_hi:[0,1]" : "=v"(d) : "v"(x)); return d;
+}
+// (a & mask) | c and (a & mask) ^ b as one instruction each
+__device__ __forceinline__ unsigned and_or(unsigned a, unsigned mask, unsigned c)
+{
+    unsigned d; asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(mask), "v"(c)); return d;
+}
+__device__ __forceinline__ unsigned and_xor(unsigned a, unsigned b, unsigned mask)
+{
+    unsigned d; asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x6c" : "=v"(d) : "v"(a), "v"(b), "s"(mask)); return d;
+}
+
 }  // namespace ldpc

@@ -317,11 +317,14 @@ static int decode_impl(ldpc_code *c, const ldpc_decode_config *cfg, const void *
         if (plain && c->has_qc && c->spec_id >= 0 && !posterior_dev) {
             Launch ioh{llr_dev, llr_dtype, (long long)frames, hard_dev, iters_dev, converged_dev, nullptr,
                        reinterpret_cast<hipStream_t>(stream)};
-            hipError_t e = launch_spec_half(c->spec_id, *cfg, ioh, c->num_cus, &g_kernel, &supported);
+            hipError_t e = cfg->rule == LDPC_RULE_LNMS
+                               ? launch_spec_lnms_half(c->spec_id, *cfg, ioh, c->num_cus, &g_kernel, &supported)
+                               : launch_spec_half(c->spec_id, *cfg, ioh, c->num_cus, &g_kernel, &supported);
             if (e != hipSuccess) return fail(LDPC_ERR_HIP, "half-precision kernel launch: %s", hipGetErrorString(e));
         }
         if (!supported)
-            return fail(LDPC_ERR_UNSUPPORTED, "the half-precision fast mode serves rule R1 on the small compiled-in codes "
+            return fail(LDPC_ERR_UNSUPPORTED, "the half-precision fast mode serves rule R1 on the small compiled-in codes and "
+                                              "layered min-sum on the compiled-in codes without double-circulant blocks "
                                               "(float LLRs, no posteriors, no loop-bound quirks, automatic kernel choice)");
         return LDPC_OK;
     }
