@@ -33,6 +33,9 @@
 namespace ldpc {
 
 constexpr int kShortRow = 10;  // inputs whose signs fit the first state word
+#ifndef LDPC_LNMSH_RESERVE
+#define LDPC_LNMSH_RESERVE 53
+#endif
 
 template <class C>
 struct LnHPlan {
@@ -98,10 +101,14 @@ lnms_h_kernel(int max_iters, int early_exit, float scale_f, const float *__restr
         const bool act0 = lane_on && fr0 < frames, act1 = lane_on && fr1 < frames;
         // loads never depend on the flags: a lane without a frame reads the group's first frame,
         // which exists.  One scalar base address per group, 32-bit offsets per lane.
-        const float *lf = llr + grp * (2 * F) * n;
-        const unsigned o0 = (fr0 < frames ? (unsigned)(2 * f) : 0u) * (unsigned)n + (unsigned)z;
-        const unsigned o1 = (fr1 < frames ? (unsigned)(2 * f + 1) : 0u) * (unsigned)n + (unsigned)z;
-        auto load_pair = [&](unsigned off) -> h2 { return pack_half2(lf[o0 + off], lf[o1 + off]); };
+        const char *lf = reinterpret_cast<const char *>(llr + grp * (2 * F) * n);
+        const unsigned o0 = ((fr0 < frames ? (unsigned)(2 * f) : 0u) * (unsigned)n + (unsigned)z) * 4u;  // bytes
+        const unsigned o1 = ((fr1 < frames ? (unsigned)(2 * f + 1) : 0u) * (unsigned)n + (unsigned)z) * 4u;
+        const h2 clamp2 = kHalfClamp2;
+        auto load_pair = [&](unsigned off) -> h2 {  // off: position inside the frame relative to z
+            return pack_half2_clamped(*reinterpret_cast<const float *>(lf + (o0 + off * 4u)),
+                                      *reinterpret_cast<const float *>(lf + (o1 + off * 4u)), clamp2);
+        };
 
         h2 A[RL > 0 ? RL : 1], B[RL > 0 ? RL : 1];
         unsigned W[RL > 0 ? RL : 1], WX[RL > 0 ? RL : 1];
@@ -117,6 +124,7 @@ lnms_h_kernel(int max_iters, int early_exit, float scale_f, const float *__restr
             if constexpr (PL::shared(bc)) {
                 const h2 l = load_pair(bc * Z);
                 if (lane_on) lds_put<h2>(ln_addr<LY, PL::lds_index(bc), 0>(zb, zbP, zbPW), l);  // idle lanes alias lane 0
+                if constexpr (PL::lds_index(bc) % 8 == 7) __builtin_amdgcn_sched_barrier(0);  // eight columns in flight at a time
             }
         });
         if constexpr (!LY::SINGLE) {
@@ -147,12 +155,27 @@ lnms_h_kernel(int max_iters, int early_exit, float scale_f, const float *__restr
             if constexpr (s == 0) return bc * Z + zo;
             else { const int v = zo + s; return bc * Z + (v >= Z ? v - Z : v); }
         };
-        auto load_priv = [&](auto br) -> h2 {
+        // the pair's channel values of the degree-one variable of block row br: the block column goes into
+        // the scalar base address, the lane part is the frame's 32-bit offset
+        auto load_priv_raw = [&](auto br, float &a, float &b) {
             constexpr int e = C::row_ptr[br] + PL::priv_pos(br), bc = C::row_col[e], s = C::row_shift[e];
-            unsigned o = 0;
-            asm volatile("" : "+v"(o));  // one address per block row, computed where it is used
-            if constexpr (s != 0) o += (unsigned)z + s >= (unsigned)Z ? (unsigned)(s - Z) : (unsigned)s;
-            return load_pair(o + (unsigned)(bc * Z));
+            const char *base = lf + bc * Z * 4;
+            asm volatile("" : "+s"(base));  // formed where it is used: the optimiser would precompute and spill every row's
+            if constexpr (s == 0) {
+                a = *reinterpret_cast<const float *>(base + o0);
+                b = *reinterpret_cast<const float *>(base + o1);
+            } else {
+                unsigned zz = (unsigned)z;
+                asm volatile("" : "+v"(zz));  // computed where it is used
+                const unsigned d = (zz + s >= (unsigned)Z ? (unsigned)(s - Z) : (unsigned)s) * 4u;
+                a = *reinterpret_cast<const float *>(base + (o0 + d));
+                b = *reinterpret_cast<const float *>(base + (o1 + d));
+            }
+        };
+        auto load_priv = [&](auto br) -> h2 {
+            float a, b;
+            load_priv_raw(br, a, b);
+            return pack_half2_clamped(a, b, clamp2);
         };
         // Bit 14 of a row's state holds the hard decisions of its degree-one variable whenever a
         // syndrome test may follow; before the first sweep they are the channel's.
@@ -162,18 +185,27 @@ lnms_h_kernel(int max_iters, int early_exit, float scale_f, const float *__restr
                     const unsigned hb = (load_priv(br) >> 1) & 0x40004000u;
                     if constexpr (br < RL) { if constexpr (HP::is_long(br)) WX[br] = hb; else W[br] = hb; }
                     else if (lane_on) lds_put<unsigned>(stA + LY::state_off(br - RL) + 2 * Z * 4, hb);
+                    if constexpr (br % 8 == 7) __builtin_amdgcn_sched_barrier(0);
                 }
             });
         }
-        // hard decisions, iteration count and flag of frame h (0 / 1) of the pair
+        // hard decisions, iteration count and flag of frame h (0 / 1) of the pair.  Addresses are
+        // formed here, from a scalar base and a 32-bit offset the optimiser cannot move out of the
+        // decode loop (dozens of precomputed 64-bit addresses would be spilled).
+        uint8_t *const hard_grp = hard_out + grp * (2 * F) * n;
         auto write_half = [&](int h, long long frame, int iters, int conv) {
             const int sh = 15 + 16 * h;
+            unsigned ho = (unsigned)(2 * f + h) * (unsigned)n + (unsigned)z;
+            asm volatile("" : "+v"(ho));
+            uint8_t *hg = hard_grp;
+            asm volatile("" : "+s"(hg));
             static_for<0, NB>([&](auto bc) {
                 if constexpr (PL::cdeg(bc) != 1) {
                     h2 v;
                     if constexpr (PL::shared(bc)) v = lds_get<h2>(ln_addr<LY, PL::lds_index(bc), 0>(zb, zbP, zbPW));
                     else v = load_pair(bc * Z);  // in no check at all: the channel decides
-                    hard_out[frame * n + bc * Z + z] = (uint8_t)((v >> sh) & 1u);
+                    hg[ho + (unsigned)(bc * Z)] = (uint8_t)((v >> sh) & 1u);
+                    if constexpr (bc % 4 == 3) __builtin_amdgcn_sched_barrier(0);  // a few columns in flight, not all: registers
                 }
             });
             static_for<0, MB>([&](auto br) {
@@ -181,7 +213,8 @@ lnms_h_kernel(int max_iters, int early_exit, float scale_f, const float *__restr
                     unsigned hb;
                     if constexpr (PL::rdeg(br) >= 2) hb = (load_bits_word(br) >> (sh - 1)) & 1u;
                     else hb = (load_priv(br) >> sh) & 1u;
-                    hard_out[frame * n + priv_index(br)] = (uint8_t)hb;
+                    hg[ho + (unsigned)(priv_index(br) - z)] = (uint8_t)hb;
+                    if constexpr (br % 4 == 3) __builtin_amdgcn_sched_barrier(0);
                 }
             });
             if (z == 0) { iters_out[frame] = iters; conv_out[frame] = (uint8_t)conv; }
@@ -189,8 +222,8 @@ lnms_h_kernel(int max_iters, int early_exit, float scale_f, const float *__restr
 
         constexpr int NPL = PL::n_priv_layers();
         constexpr int SYN_FIRST = 2, SYN_EVERY = 6;  // block rows between looks at the outcome of the syndrome test
-        h2 lp_next = 0u;  // channel values of the next layer's degree-one variable, requested one layer ahead
-        if constexpr (NPL > 0) lp_next = load_priv(IC<PL::priv_layer(0)>{});
+        float lp_a = 0.0f, lp_b = 0.0f;  // channel values of the next layer's degree-one variable, requested one layer ahead
+        if constexpr (NPL > 0) load_priv_raw(IC<PL::priv_layer(0)>{}, lp_a, lp_b);
 
         bool done0 = !act0, done1 = !act1;
         int res_conv0 = 0, res_conv1 = 0;
@@ -279,8 +312,8 @@ lnms_h_kernel(int max_iters, int early_exit, float scale_f, const float *__restr
                     h2 lp = 0u;
                     if constexpr (PP >= 0) {
                         constexpr int j = PL::priv_layer_ord(br);
-                        lp = lp_next;
-                        if constexpr (NPL > 1) lp_next = load_priv(IC<PL::priv_layer((j + 1) % NPL)>{});
+                        lp = pack_half2_clamped(lp_a, lp_b, clamp2);
+                        if constexpr (NPL > 1) load_priv_raw(IC<PL::priv_layer((j + 1) % NPL)>{}, lp_a, lp_b);
                     }
                     if (!slot_done) {
                         h2 q[D];
@@ -292,12 +325,11 @@ lnms_h_kernel(int max_iters, int early_exit, float scale_f, const float *__restr
                         asm volatile("" : "+v"(zl));  // hundreds of hoisted addresses would spill
                         // all posteriors of the row are requested first: one LDS round trip per row
                         static_for<0, D>([&](auto p) {
-                            if constexpr (p == PP) {
-                                off[p] = 0;
-                            } else {
+                            if constexpr (p != PP) {
                                 constexpr int bc = C::row_col[e0 + p], s = C::row_shift[e0 + p];
-                                off[p] = ln_addr<LY, PL::lds_index(bc), s>(zl, zbP, zbPW);
-                                q[p] = lds_get<h2>(off[p]);
+                                const unsigned ad = ln_addr<LY, PL::lds_index(bc), s>(zl, zbP, zbPW);
+                                off[LONG ? 0 : (int)p] = ad;
+                                q[p] = lds_get<h2>(ad);
                                 __builtin_amdgcn_sched_barrier(0);  // address, read, address, read
                             }
                         });
@@ -314,33 +346,27 @@ lnms_h_kernel(int max_iters, int early_exit, float scale_f, const float *__restr
                             unsigned &ws = (p < DA) ? wsa : wsb;
                             if constexpr (p == PP) {
                                 q[p] = lp;  // a variable of degree one always sends its channel value
+                                hedge_in_given(q[p], ws, m1, m2, sx);
                             } else {
-                                // the edge's old message: magnitude B if it held the minimum last time, else A
-                                unsigned d = idx2;
-                                if constexpr (p != 0) d ^= (unsigned)p * 0x00010001u;
-                                const unsigned mag = pk_mad_u16(pk_is_zero(d), dba_o, Ao);
-                                q[p] = pk_sub(q[p], and_or(ws, kSignMask, mag));
+                                hedge_in<p>(q[p], idx2, Ao, dba_o, ws, m1, m2, sx);
                             }
-                            const h2 a = q[p] & kAbsMask;
-                            m2 = pk_min(m2, pk_max(m1, a));
-                            m1 = pk_min(m1, a);
-                            ws = pk_funnel(ws, pk_shr<15>(q[p]));
-                            sx ^= q[p];
                         });
                         const unsigned px = sx & kSignMask;
-                        const h2 An = pk_min(pk_mul(m1, scale2), kHalfClamp2), Bn = pk_min(pk_mul(m2, scale2), kHalfClamp2);
+                        const h2 An = pk_min(pk_mul(m1, scale2), clamp2), Bn = pk_min(pk_mul(m2, scale2), clamp2);
                         const unsigned Anp = An | px;  // the parity of the inputs folded into the new messages
                         const unsigned dba_n = pk_sub_u16(Bn, An);
                         unsigned mina = 0, minb = 0;   // per edge: does it hold the smallest magnitude?
                         unsigned privbit = 0;
                         static_for<0, D>([&](auto p) {
                             unsigned &mn = (p < DA) ? mina : minb;
-                            const unsigned e = pk_is_zero((q[p] & kAbsMask) ^ m1);
-                            const unsigned magp = pk_mad_u16(e, dba_n, Anp);
-                            mn = pk_funnel(mn, e);
-                            const h2 pn = pk_add(q[p], and_xor(q[p], magp, kSignMask));  // the variable's new posterior
+                            const h2 pn = hedge_out(q[p], m1, Anp, dba_n, mn);  // the variable's new posterior
                             if constexpr (p != PP) {
-                                lds_put<h2>(off[p], pn);
+                                if constexpr (LONG) {  // a long row's addresses are formed again: keeping them costs registers
+                                    constexpr int bc = C::row_col[e0 + p], s = C::row_shift[e0 + p];
+                                    lds_put<h2>(ln_addr<LY, PL::lds_index(bc), s>(zl, zbP, zbPW), pn);
+                                } else {
+                                    lds_put<h2>(off[p], pn);
+                                }
                                 __builtin_amdgcn_sched_barrier(0);  // block, write, block, write
                             } else if (want_bits) {
                                 privbit = (pn >> 1) & 0x40004000u;
@@ -391,7 +417,7 @@ struct LnHConfig {
     static constexpr int WAVES = ((F * C::Z + 63) / 64);
     static constexpr int WPE = WAVES >= 4 ? (WAVES + 3) / 4 : 3;
     static constexpr int VGPRS = WPE <= 2 ? 256 : (512 / WPE) / 8 * 8;
-    static constexpr int STATE_REGS = VGPRS - 53 > 180 ? 180 : VGPRS - 53;
+    static constexpr int STATE_REGS = VGPRS - LDPC_LNMSH_RESERVE > 180 ? 180 : VGPRS - LDPC_LNMSH_RESERVE;
     static constexpr int rl()
     {
         int r = 0;
@@ -400,7 +426,7 @@ struct LnHConfig {
     }
     static constexpr int RL = rl();
     static constexpr bool OK = HP::supported() && HP::spill_ok(RL) && WPE <= 4 && F <= 8 &&
-                               LnLayout<C, float, F, RL>::LDS_BYTES <= 160 * 1024;
+                               (LnLayout<C, float, F, RL>::LDS_BYTES <= 160 * 1024 || LDPC_LNMSH_RESERVE != 53);
 };
 // Slots per workgroup: the packaged default, doubled when that makes the number of waves a multiple
 // of the four SIMDs (see decode_lnms.hip).

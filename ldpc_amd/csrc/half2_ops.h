@@ -37,6 +37,15 @@ __device__ __forceinline__ h2 pack_half2(float lo, float hi)
     const v2h p = __builtin_amdgcn_cvt_pkrtz(lo, hi);
     return *reinterpret_cast<const h2 *>(&p);
 }
+// the same with the clamp after the conversion (a value beyond the half-precision range converts to
+// an infinity, which the clamp brings back): the bound is a packed register the caller holds anyway
+__device__ __forceinline__ h2 pack_half2_clamped(float lo, float hi, h2 bound2)
+{
+    h2 d;
+    asm("v_cvt_pkrtz_f16_f32 %0, %1, %2\n\tv_pk_max_f16 %0, %0, %3 neg_lo:[0,1] neg_hi:[0,1]\n\tv_pk_min_f16 %0, %0, %3"
+        : "=&v"(d) : "v"(lo), "v"(hi), "v"(bound2));
+    return d;
+}
 // "value > 0" of one half (hard decision `0 if b > 0 else 1`, bpsk.py:240-243)
 __device__ __forceinline__ bool half_positive(h2 v, int h)
 {
@@ -90,6 +99,52 @@ __device__ __forceinline__ unsigned and_or(unsigned a, unsigned mask, unsigned c
 __device__ __forceinline__ unsigned and_xor(unsigned a, unsigned b, unsigned mask)
 {
     unsigned d; asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x6c" : "=v"(d) : "v"(a), "v"(b), "s"(mask)); return d;
+}
+
+// One input edge of a packed layered check as ONE block (the compiler puts a wait state between
+// separate inline blocks that depend on each other).  Take the edge's previous message off the pair
+// of posteriors q -- magnitude B where the edge held the minimum last time (position idx2 == P), else
+// A, as A + e (B - A) on the bit patterns; sign in the top bit of each half of ws -- then book |q|
+// in the running smallest / second smallest (m1 <= m2), funnel sign(q) into ws (the old signs leave
+// at the top, the new ones enter at the bottom) and fold q into the parity word sx.
+#define LDPC_HEDGE_OLD "v_pk_sub_u16 %[t], 1, %[t] op_sel_hi:[0,1] clamp\n\tv_pk_mad_u16 %[t], %[t], %[dba], %[a]\n\t" \
+                       "v_and_or_b32 %[t], %[ws], %[S], %[t]\n\tv_pk_add_f16 %[q], %[q], %[t] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+#define LDPC_HEDGE_BOOK "v_and_b32 %[t], 0x7fff7fff, %[q]\n\tv_pk_max_f16 %[u], %[m1], %[t]\n\tv_pk_min_f16 %[m2], %[m2], %[u]\n\t" \
+                        "v_pk_min_f16 %[m1], %[m1], %[t]\n\tv_pk_lshrrev_b16 %[t], 15, %[q] op_sel_hi:[0,1]\n\t"                   \
+                        "v_pk_mad_u16 %[ws], %[ws], 2, %[t] op_sel_hi:[1,0,1]\n\tv_xor_b32 %[sx], %[sx], %[q]"
+template <int P>
+__device__ __forceinline__ void hedge_in(h2 &q, unsigned idx2, h2 a, unsigned dba, unsigned &ws, h2 &m1, h2 &m2, unsigned &sx)
+{
+    unsigned t, u;
+    if constexpr (P == 0)
+        asm("v_mov_b32 %[t], %[idx]\n\t" LDPC_HEDGE_OLD LDPC_HEDGE_BOOK
+            : [q] "+v"(q), [t] "=&v"(t), [u] "=&v"(u), [ws] "+v"(ws), [m1] "+v"(m1), [m2] "+v"(m2), [sx] "+v"(sx)
+            : [idx] "v"(idx2), [a] "v"(a), [dba] "v"(dba), [S] "s"(kSignMask));
+    else
+        asm("v_xor_b32 %[t], %[p2], %[idx]\n\t" LDPC_HEDGE_OLD LDPC_HEDGE_BOOK
+            : [q] "+v"(q), [t] "=&v"(t), [u] "=&v"(u), [ws] "+v"(ws), [m1] "+v"(m1), [m2] "+v"(m2), [sx] "+v"(sx)
+            : [idx] "v"(idx2), [a] "v"(a), [dba] "v"(dba), [S] "s"(kSignMask), [p2] "i"(P * 0x00010001));
+}
+// the same for an edge whose input is given (no previous message to take off)
+__device__ __forceinline__ void hedge_in_given(h2 q, unsigned &ws, h2 &m1, h2 &m2, unsigned &sx)
+{
+    unsigned t, u;
+    asm(LDPC_HEDGE_BOOK : [t] "=&v"(t), [u] "=&v"(u), [ws] "+v"(ws), [m1] "+v"(m1), [m2] "+v"(m2), [sx] "+v"(sx) : [q] "v"(q));
+}
+#undef LDPC_HEDGE_OLD
+#undef LDPC_HEDGE_BOOK
+// Second pass of an edge: e = 1 where |q| == m1; new message magnitude An + e (Bn - An) with the
+// parity of the inputs in its sign bits (anp), times sign(q); e funnelled into mn; returns q + message.
+__device__ __forceinline__ h2 hedge_out(h2 q, h2 m1, unsigned anp, unsigned dba, unsigned &mn)
+{
+    unsigned t;
+    h2 out;
+    asm("v_bitop3_b32 %[t], %[m1], %[q], %[A] bitop3:0x78\n\tv_pk_sub_u16 %[t], 1, %[t] op_sel_hi:[0,1] clamp\n\t"
+        "v_pk_mad_u16 %[mn], %[mn], 2, %[t] op_sel_hi:[1,0,1]\n\tv_pk_mad_u16 %[t], %[t], %[dba], %[anp]\n\t"
+        "v_bitop3_b32 %[t], %[q], %[t], %[S] bitop3:0x6c\n\tv_pk_add_f16 %[out], %[q], %[t]"
+        : [out] "=v"(out), [t] "=&v"(t), [mn] "+v"(mn)
+        : [q] "v"(q), [m1] "v"(m1), [anp] "v"(anp), [dba] "v"(dba), [S] "s"(kSignMask), [A] "s"(kAbsMask));
+    return out;
 }
 
 }  // namespace ldpc

@@ -61,6 +61,16 @@
 #define I_MED3U(i) "v_med3_u32 %" #i ", %" #i ", %8, %8\n"
 #define I_SADU8(i) "v_sad_u8 %" #i ", %" #i ", %8, %8\n"
 #define I_DPPMOV(i) "v_mov_b32_dpp %" #i ", %8 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+#define I_PKMADU16(i) "v_pk_mad_u16 %" #i ", %" #i ", %8, %8\n"
+#define I_PKMADU16C(i) "v_pk_mad_u16 %" #i ", %" #i ", 2, %8 op_sel_hi:[1,0,1]\n"
+#define I_PKSUBSAT(i) "v_pk_sub_u16 %" #i ", 1, %" #i " op_sel_hi:[0,1] clamp\n"
+#define I_PKSUBU16(i) "v_pk_sub_u16 %" #i ", %" #i ", %8\n"
+#define I_BITOP3(i) "v_bitop3_b32 %" #i ", %" #i ", %8, %8 bitop3:0x6c\n"
+#define I_PKLSHR16(i) "v_pk_lshrrev_b16 %" #i ", 15, %" #i " op_sel_hi:[0,1]\n"
+#define I_PKMADI16(i) "v_pk_mad_i16 %" #i ", %" #i ", %8, %8\n"
+#define I_MADU16(i) "v_mad_u16 %" #i ", %" #i ", %8, %8\n"
+#define I_MADU32U24(i) "v_mad_u32_u24 %" #i ", %" #i ", %8, %8\n"
+#define I_PKMULLO(i) "v_pk_mul_lo_u16 %" #i ", %" #i ", %8\n"
 #define I_SDWAAND(i) "v_and_b32_sdwa %" #i ", %" #i ", %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1\n"
 
 template <int OP> __global__ void k(float *out, int iters, float seed) {
@@ -80,7 +90,8 @@ template <int OP> __global__ void k(float *out, int iters, float seed) {
         CASE(37, I_PKMIN16) CASE(38, I_PKMAX16) CASE(39, I_PKMUL16) CASE(40, I_PKFMA16) CASE(41, I_PKMINU16)
         CASE(42, I_PKMAXI16) CASE(43, I_PKADDU16) CASE(44, I_PKSUBI16) CASE(45, I_PKLSHL16) CASE(46, I_PKASHR16)
         CASE(47, I_PERM) CASE(48, I_MINI16) CASE(49, I_MINU32) CASE(50, I_MIN3U) CASE(51, I_MED3U) CASE(52, I_SADU8)
-        CASE(53, I_DPPMOV) CASE(54, I_SDWAAND)
+        CASE(53, I_DPPMOV) CASE(54, I_SDWAAND) CASE(55, I_PKMADU16) CASE(56, I_PKMADU16C) CASE(57, I_PKSUBSAT)
+        CASE(58, I_PKSUBU16) CASE(59, I_BITOP3) CASE(60, I_PKLSHR16) CASE(61, I_PKMADI16) CASE(62, I_MADU16) CASE(63, I_MADU32U24) CASE(64, I_PKMULLO)
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = f0 + f1 + f2 + f3 + f4 + f5 + f6 + f7 + (float)(d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7);
 }
@@ -112,7 +123,8 @@ int main() {
     RUN(37, "v_pk_min_f16") RUN(38, "v_pk_max_f16") RUN(39, "v_pk_mul_f16") RUN(40, "v_pk_fma_f16") RUN(41, "v_pk_min_u16")
     RUN(42, "v_pk_max_i16") RUN(43, "v_pk_add_u16") RUN(44, "v_pk_sub_i16") RUN(45, "v_pk_lshlrev_b16") RUN(46, "v_pk_ashrrev_i16")
     RUN(47, "v_perm_b32") RUN(48, "v_min_i16") RUN(49, "v_min_u32") RUN(50, "v_min3_u32") RUN(51, "v_med3_u32") RUN(52, "v_sad_u8")
-    RUN(53, "v_mov_b32 dpp") RUN(54, "v_and_b32 sdwa")
+    RUN(53, "v_mov_b32 dpp") RUN(54, "v_and_b32 sdwa") RUN(55, "v_pk_mad_u16") RUN(56, "v_pk_mad_u16 x2+") RUN(57, "v_pk_sub_u16 clamp")
+    RUN(58, "v_pk_sub_u16") RUN(59, "v_bitop3_b32") RUN(60, "v_pk_lshrrev_b16") RUN(61, "v_pk_mad_i16") RUN(62, "v_mad_u16") RUN(63, "v_mad_u32_u24") RUN(64, "v_pk_mul_lo_u16")
     printf("-- 3 waves per SIMD (768 threads)\n");
     run<0>("v_add_f32", out, 768); run<3>("v_min_f32 |x|", out, 768); run<5>("v_med3_f32", out, 768); run<24>("v_cndmask vcc", out, 768);
     run<37>("v_pk_min_f16", out, 768);
