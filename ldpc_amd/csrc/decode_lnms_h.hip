@@ -15,7 +15,10 @@
 // patterns instead: with e = 1 where a 16-bit difference is zero (one saturating subtraction) the
 // magnitude is A + e (B - A) in INTEGER arithmetic (v_pk_mad_u16), exact for positive half-precision
 // patterns.  Check state of one pair:
-//   A, B   scale * smallest / second smallest input magnitude, clamped to 2000
+//   AB     scale * smallest / second smallest input magnitude, clamped to 2000 and cut to the upper
+//          eight of their fifteen magnitude bits (five exponent, three mantissa bits), per frame A in
+//          the low byte and B in the high byte of its half.  The cut values are the messages that are
+//          added to the posteriors as well: what a layer adds is exactly what its next visit takes off.
 //   W      per frame 16 bits: bit 15 sign parity of the inputs | bit 14 hard decision of the check's
 //          degree-one variable | bits 13-10 position of the smallest input | bits 9-0 input signs
 //          (first edge highest).  Checks of more than ten inputs keep a second word for the signs of
@@ -33,6 +36,8 @@
 namespace ldpc {
 
 constexpr int kShortRow = 10;  // inputs whose signs fit the first state word
+constexpr unsigned kMagCut = 0x7f807f80u;  // the upper eight magnitude bits of both halves
+constexpr unsigned kMagHalfStep = 0x00400040u;  // half of the lowest kept bit: no carry leaves a half (magnitudes <= 2000)
 #ifndef LDPC_LNMSH_RESERVE
 #define LDPC_LNMSH_RESERVE 53
 #endif
@@ -42,7 +47,7 @@ struct LnHPlan {
     typedef LnPlan<C> PL;
     static constexpr bool is_long(int br) { return PL::rdeg(br) > kShortRow; }
     static constexpr int da(int br) { return is_long(br) ? kShortRow : PL::rdeg(br); }
-    static constexpr int words(int br) { return is_long(br) ? 4 : 3; }
+    static constexpr int words(int br) { return is_long(br) ? 3 : 2; }
     static constexpr bool supported() { return PL::supported() && C::MAX_DC <= 2 * kShortRow; }
     // registers taken by the state of block rows [0, rl)
     static constexpr int regs(int rl)
@@ -51,7 +56,7 @@ struct LnHPlan {
         for (int r = 0; r < rl && r < C::MB; ++r) c += words(r);
         return c;
     }
-    // block rows [rl, MB) keep their state in LDS as three words: none of them may be long
+    // block rows [rl, MB) keep their state in LDS as two words: none of them may be long
     static constexpr bool spill_ok(int rl)
     {
         for (int r = rl; r < C::MB; ++r) if (is_long(r)) return false;
@@ -104,19 +109,17 @@ lnms_h_kernel(int max_iters, int early_exit, float scale_f, const float *__restr
         const char *lf = reinterpret_cast<const char *>(llr + grp * (2 * F) * n);
         const unsigned o0 = ((fr0 < frames ? (unsigned)(2 * f) : 0u) * (unsigned)n + (unsigned)z) * 4u;  // bytes
         const unsigned o1 = ((fr1 < frames ? (unsigned)(2 * f + 1) : 0u) * (unsigned)n + (unsigned)z) * 4u;
-        const h2 clamp2 = kHalfClamp2;
+        const h2 clamp2 = kHalfClamp2, big2 = kHalfMax2;
         auto load_pair = [&](unsigned off) -> h2 {  // off: position inside the frame relative to z
             return pack_half2_clamped(*reinterpret_cast<const float *>(lf + (o0 + off * 4u)),
                                       *reinterpret_cast<const float *>(lf + (o1 + off * 4u)), clamp2);
         };
 
-        h2 A[RL > 0 ? RL : 1], B[RL > 0 ? RL : 1];
-        unsigned W[RL > 0 ? RL : 1], WX[RL > 0 ? RL : 1];
+        unsigned AB[RL > 0 ? RL : 1], W[RL > 0 ? RL : 1], WX[RL > 0 ? RL : 1];
         static_for<0, MB>([&](auto br) {
-            if constexpr (br < RL) { A[br] = 0u; B[br] = 0u; W[br] = 0u; WX[br] = 0u; }
+            if constexpr (br < RL) { AB[br] = 0u; W[br] = 0u; WX[br] = 0u; }
             else if (lane_on) {
                 lds_put<unsigned>(stA + LY::state_off(br - RL), 0u);
-                lds_put<unsigned>(stA + LY::state_off(br - RL) + Z * 4, 0u);
                 lds_put<unsigned>(stA + LY::state_off(br - RL) + 2 * Z * 4, 0u);
             }
         });
@@ -134,11 +137,10 @@ lnms_h_kernel(int max_iters, int early_exit, float scale_f, const float *__restr
 
         // wx: the second state word of a long row, and the word that holds bit 14 (the hard decision
         // of the row's degree-one variable) in either case
-        auto load_state = [&](auto br, h2 &a, h2 &b, unsigned &w, unsigned &wx) {
-            if constexpr (br < RL) { a = A[br]; b = B[br]; w = W[br]; wx = HP::is_long(br) ? WX[br] : w; }
+        auto load_state = [&](auto br, unsigned &ab, unsigned &w, unsigned &wx) {
+            if constexpr (br < RL) { ab = AB[br]; w = W[br]; wx = HP::is_long(br) ? WX[br] : w; }
             else {
-                a = lds_get<h2>(stA + LY::state_off(br - RL));
-                b = lds_get<h2>(stA + LY::state_off(br - RL) + Z * 4);
+                ab = lds_get<unsigned>(stA + LY::state_off(br - RL));
                 w = lds_get<unsigned>(stA + LY::state_off(br - RL) + 2 * Z * 4);
                 wx = w;
             }
@@ -159,8 +161,9 @@ lnms_h_kernel(int max_iters, int early_exit, float scale_f, const float *__restr
         // the scalar base address, the lane part is the frame's 32-bit offset
         auto load_priv_raw = [&](auto br, float &a, float &b) {
             constexpr int e = C::row_ptr[br] + PL::priv_pos(br), bc = C::row_col[e], s = C::row_shift[e];
-            const char *base = lf + bc * Z * 4;
-            asm volatile("" : "+s"(base));  // formed where it is used: the optimiser would precompute and spill every row's
+            unsigned cb = bc * Z * 4;
+            asm volatile("" : "+s"(cb));  // formed where it is used: the optimiser would precompute and spill every row's
+            const char *base = lf + cb;
             if constexpr (s == 0) {
                 a = *reinterpret_cast<const float *>(base + o0);
                 b = *reinterpret_cast<const float *>(base + o1);
@@ -197,8 +200,9 @@ lnms_h_kernel(int max_iters, int early_exit, float scale_f, const float *__restr
             const int sh = 15 + 16 * h;
             unsigned ho = (unsigned)(2 * f + h) * (unsigned)n + (unsigned)z;
             asm volatile("" : "+v"(ho));
-            uint8_t *hg = hard_grp;
-            asm volatile("" : "+s"(hg));
+            unsigned zero = 0;
+            asm volatile("" : "+s"(zero));
+            uint8_t *hg = hard_grp + zero;
             static_for<0, NB>([&](auto bc) {
                 if constexpr (PL::cdeg(bc) != 1) {
                     h2 v;
@@ -318,9 +322,9 @@ lnms_h_kernel(int max_iters, int early_exit, float scale_f, const float *__restr
                     if (!slot_done) {
                         h2 q[D];
                         unsigned off[D];
-                        h2 Ao, Bo;
-                        unsigned w, wx;
-                        load_state(br, Ao, Bo, w, wx);
+                        unsigned ab, w, wx;
+                        load_state(br, ab, w, wx);
+                        const h2 Ao = pk_shl<7>(ab) & kMagCut, Bo = pk_shr<1>(ab) & kMagCut;
                         unsigned zl = zb;
                         asm volatile("" : "+v"(zl));  // hundreds of hoisted addresses would spill
                         // all posteriors of the row are requested first: one LDS round trip per row
@@ -333,26 +337,29 @@ lnms_h_kernel(int max_iters, int early_exit, float scale_f, const float *__restr
                                 __builtin_amdgcn_sched_barrier(0);  // address, read, address, read
                             }
                         });
-                        const unsigned idx2 = pk_shr<10>(w) & (LONG ? 0x001f001fu : 0x000f000fu);
+                        // position of the previous minimum, counted down edge by edge: zero at its own edge
+                        unsigned cnt = pk_shr<10>(w) & (LONG ? 0x001f001fu : 0x000f000fu);
                         const unsigned dba_o = pk_sub_u16(Bo, Ao);
                         // bit 15 of a half of wsa / wsb: sign of the old message on the current edge.  Every edge
                         // shifts it out and the sign of its input in at the bottom: the words end as the new signs.
                         unsigned wsa = pk_shl<16 - DA>(w ^ pk_sign_fill(w));
                         unsigned wsb = 0;
                         if constexpr (LONG) wsb = pk_shl<16 - DB>(wx ^ pk_sign_fill(wx));
-                        h2 m1 = kHalfMax2, m2 = kHalfMax2;
-                        unsigned sx = 0;  // sign parity of the inputs (bits 15 and 31)
+                        h2 m1, m2;
+                        unsigned sx;  // sign parity of the inputs (bits 15 and 31)
                         static_for<0, D>([&](auto p) {
                             unsigned &ws = (p < DA) ? wsa : wsb;
                             if constexpr (p == PP) {
                                 q[p] = lp;  // a variable of degree one always sends its channel value
-                                hedge_in_given(q[p], ws, m1, m2, sx);
+                                hedge_in_given<p == 0>(q[p], cnt, ws, m1, m2, sx, big2);
                             } else {
-                                hedge_in<p>(q[p], idx2, Ao, dba_o, ws, m1, m2, sx);
+                                hedge_in<p == 0>(q[p], cnt, Ao, dba_o, ws, m1, m2, sx, big2);
                             }
                         });
                         const unsigned px = sx & kSignMask;
-                        const h2 An = pk_min(pk_mul(m1, scale2), clamp2), Bn = pk_min(pk_mul(m2, scale2), clamp2);
+                        // cut to eight magnitude bits, rounded to nearest (half a step added first)
+                        const h2 An = (pk_min(pk_mul(m1, scale2), clamp2) + kMagHalfStep) & kMagCut;
+                        const h2 Bn = (pk_min(pk_mul(m2, scale2), clamp2) + kMagHalfStep) & kMagCut;
                         const unsigned Anp = An | px;  // the parity of the inputs folded into the new messages
                         const unsigned dba_n = pk_sub_u16(Bn, An);
                         unsigned mina = 0, minb = 0;   // per edge: does it hold the smallest magnitude?
@@ -387,12 +394,12 @@ lnms_h_kernel(int max_iters, int early_exit, float scale_f, const float *__restr
                         unsigned wxn = 0;
                         if constexpr (LONG) wxn = wsb | px | privbit;
                         else wn |= privbit;
+                        const unsigned abn = pk_shr<7>(An) | (Bn << 1);
                         if constexpr (br < RL) {
-                            A[br] = An; B[br] = Bn; W[br] = wn;
+                            AB[br] = abn; W[br] = wn;
                             if constexpr (LONG) WX[br] = wxn;
                         } else {
-                            lds_put<h2>(stA + LY::state_off(br - RL), An);
-                            lds_put<h2>(stA + LY::state_off(br - RL) + Z * 4, Bn);
+                            lds_put<unsigned>(stA + LY::state_off(br - RL), abn);
                             lds_put<unsigned>(stA + LY::state_off(br - RL) + 2 * Z * 4, wn);
                         }
                     }

@@ -103,36 +103,48 @@ __device__ __forceinline__ unsigned and_xor(unsigned a, unsigned b, unsigned mas
 
 // One input edge of a packed layered check as ONE block (the compiler puts a wait state between
 // separate inline blocks that depend on each other).  Take the edge's previous message off the pair
-// of posteriors q -- magnitude B where the edge held the minimum last time (position idx2 == P), else
-// A, as A + e (B - A) on the bit patterns; sign in the top bit of each half of ws -- then book |q|
-// in the running smallest / second smallest (m1 <= m2), funnel sign(q) into ws (the old signs leave
-// at the top, the new ones enter at the bottom) and fold q into the parity word sx.
-#define LDPC_HEDGE_OLD "v_pk_sub_u16 %[t], 1, %[t] op_sel_hi:[0,1] clamp\n\tv_pk_mad_u16 %[t], %[t], %[dba], %[a]\n\t" \
-                       "v_and_or_b32 %[t], %[ws], %[S], %[t]\n\tv_pk_add_f16 %[q], %[q], %[t] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+// of posteriors q -- magnitude B where the edge held the minimum last time, else A, as A + e (B - A)
+// on the bit patterns, e = 1 where the running counter c (position of that minimum minus the edge's
+// own position, per half) is zero; sign in the top bit of each half of ws -- then book |q| in the
+// running smallest / second smallest (m1 <= m2), funnel sign(q) into ws (the old signs leave at the
+// top, the new ones enter at the bottom) and fold q into the parity word sx.  FIRST: the check's
+// first edge (m1, m2 and sx start here; big = the largest half-precision number twice).
+#define LDPC_HEDGE_OLD "v_pk_sub_u16 %[t], 1, %[c] op_sel_hi:[0,1] clamp\n\tv_pk_sub_u16 %[c], %[c], 1 op_sel_hi:[1,0]\n\t" \
+                       "v_pk_mad_u16 %[t], %[t], %[dba], %[a]\n\tv_and_or_b32 %[t], %[ws], %[S], %[t]\n\t"                   \
+                       "v_pk_add_f16 %[q], %[q], %[t] neg_lo:[0,1] neg_hi:[0,1]\n\t"
 #define LDPC_HEDGE_BOOK "v_and_b32 %[t], 0x7fff7fff, %[q]\n\tv_pk_max_f16 %[u], %[m1], %[t]\n\tv_pk_min_f16 %[m2], %[m2], %[u]\n\t" \
                         "v_pk_min_f16 %[m1], %[m1], %[t]\n\tv_pk_lshrrev_b16 %[t], 15, %[q] op_sel_hi:[0,1]\n\t"                   \
                         "v_pk_mad_u16 %[ws], %[ws], 2, %[t] op_sel_hi:[1,0,1]\n\tv_xor_b32 %[sx], %[sx], %[q]"
-template <int P>
-__device__ __forceinline__ void hedge_in(h2 &q, unsigned idx2, h2 a, unsigned dba, unsigned &ws, h2 &m1, h2 &m2, unsigned &sx)
+#define LDPC_HEDGE_BOOK1 "v_and_b32 %[m1], 0x7fff7fff, %[q]\n\tv_mov_b32 %[m2], %[big]\n\tv_pk_lshrrev_b16 %[t], 15, %[q] op_sel_hi:[0,1]\n\t" \
+                         "v_pk_mad_u16 %[ws], %[ws], 2, %[t] op_sel_hi:[1,0,1]\n\tv_mov_b32 %[sx], %[q]"
+template <bool FIRST>
+__device__ __forceinline__ void hedge_in(h2 &q, unsigned &c, h2 a, unsigned dba, unsigned &ws, h2 &m1, h2 &m2, unsigned &sx, h2 big)
 {
     unsigned t, u;
-    if constexpr (P == 0)
-        asm("v_mov_b32 %[t], %[idx]\n\t" LDPC_HEDGE_OLD LDPC_HEDGE_BOOK
-            : [q] "+v"(q), [t] "=&v"(t), [u] "=&v"(u), [ws] "+v"(ws), [m1] "+v"(m1), [m2] "+v"(m2), [sx] "+v"(sx)
-            : [idx] "v"(idx2), [a] "v"(a), [dba] "v"(dba), [S] "s"(kSignMask));
+    if constexpr (FIRST)
+        asm(LDPC_HEDGE_OLD LDPC_HEDGE_BOOK1
+            : [q] "+v"(q), [c] "+v"(c), [t] "=&v"(t), [ws] "+v"(ws), [m1] "=&v"(m1), [m2] "=&v"(m2), [sx] "=&v"(sx)
+            : [a] "v"(a), [dba] "v"(dba), [S] "s"(kSignMask), [big] "v"(big));
     else
-        asm("v_xor_b32 %[t], %[p2], %[idx]\n\t" LDPC_HEDGE_OLD LDPC_HEDGE_BOOK
-            : [q] "+v"(q), [t] "=&v"(t), [u] "=&v"(u), [ws] "+v"(ws), [m1] "+v"(m1), [m2] "+v"(m2), [sx] "+v"(sx)
-            : [idx] "v"(idx2), [a] "v"(a), [dba] "v"(dba), [S] "s"(kSignMask), [p2] "i"(P * 0x00010001));
+        asm(LDPC_HEDGE_OLD LDPC_HEDGE_BOOK
+            : [q] "+v"(q), [c] "+v"(c), [t] "=&v"(t), [u] "=&v"(u), [ws] "+v"(ws), [m1] "+v"(m1), [m2] "+v"(m2), [sx] "+v"(sx)
+            : [a] "v"(a), [dba] "v"(dba), [S] "s"(kSignMask));
 }
-// the same for an edge whose input is given (no previous message to take off)
-__device__ __forceinline__ void hedge_in_given(h2 q, unsigned &ws, h2 &m1, h2 &m2, unsigned &sx)
+// the same for an edge whose input is given (no previous message to take off); the counter still moves on
+template <bool FIRST>
+__device__ __forceinline__ void hedge_in_given(h2 q, unsigned &c, unsigned &ws, h2 &m1, h2 &m2, unsigned &sx, h2 big)
 {
     unsigned t, u;
-    asm(LDPC_HEDGE_BOOK : [t] "=&v"(t), [u] "=&v"(u), [ws] "+v"(ws), [m1] "+v"(m1), [m2] "+v"(m2), [sx] "+v"(sx) : [q] "v"(q));
+    if constexpr (FIRST)
+        asm("v_pk_sub_u16 %[c], %[c], 1 op_sel_hi:[1,0]\n\t" LDPC_HEDGE_BOOK1
+            : [c] "+v"(c), [t] "=&v"(t), [ws] "+v"(ws), [m1] "=&v"(m1), [m2] "=&v"(m2), [sx] "=&v"(sx) : [q] "v"(q), [big] "v"(big));
+    else
+        asm("v_pk_sub_u16 %[c], %[c], 1 op_sel_hi:[1,0]\n\t" LDPC_HEDGE_BOOK
+            : [c] "+v"(c), [t] "=&v"(t), [u] "=&v"(u), [ws] "+v"(ws), [m1] "+v"(m1), [m2] "+v"(m2), [sx] "+v"(sx) : [q] "v"(q));
 }
 #undef LDPC_HEDGE_OLD
 #undef LDPC_HEDGE_BOOK
+#undef LDPC_HEDGE_BOOK1
 // Second pass of an edge: e = 1 where |q| == m1; new message magnitude An + e (Bn - An) with the
 // parity of the inputs in its sign bits (anp), times sign(q); e funnelled into mn; returns q + message.
 __device__ __forceinline__ h2 hedge_out(h2 q, h2 m1, unsigned anp, unsigned dba, unsigned &mn)
