@@ -78,7 +78,7 @@ def _profile_record(kind, key, fixed, kernel):
 
 def rooflines(code, cfg, dtype, frames, kernel_ms, executed, kernel, code_name, rule_name, fused=False):
     """HBM, LDS and vector-issue rooflines of one launch."""
-    itemsize = 8 if dtype == "f64" else 4
+    itemsize = {"f64": 8, "f32": 4, "f16": 2}[dtype]
     key = f"{code_name}/{rule_name}/{dtype}/" + ("fused" if fused else "f32llr")
     fixed = not cfg.early_exit
     sec = kernel_ms * 1e-3
@@ -209,7 +209,7 @@ def cpu_baseline(code, cfg, batch, k_info, dtype, seconds, cpu_sample=0):
     same = (np.array_equal(hard, batch.hard[:sample].cpu().numpy())
             and np.array_equal(iters, batch.iters[:sample].cpu().numpy())
             and np.array_equal(conv, batch.converged[:sample].cpu().numpy().astype(bool)))
-    exact = dtype == "f64" or cfg.rule == 5
+    exact = dtype != "f16" and (dtype == "f64" or cfg.rule == 5)
     return {"value": sample * k_info / dt / 1e9, "unit": "Gbit/s", "cores": threads, "kind": "port",
             "sample": f"first {sample} frames of the same LLR batch, "
                       f"{'float32' if (cfg.rule == 5 and dtype == 'f32') else 'float64'}, oracle/bp_oracle.c with "
@@ -226,7 +226,7 @@ def main():
                     "small codes, 16384 for the NR graphs)")
     ap.add_argument("--code", default="ccsds512")
     ap.add_argument("--rule", default="R0")
-    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32", "f16"], help="arithmetic type; f16 = packed half precision, two frames per lane (reduced-precision fast mode of R1 and LNMS)")
     ap.add_argument("--snr", type=float, default=1.0, help="Es/N0 in dB of the synthetic channel")
     ap.add_argument("--max-iters", type=int, default=10)
     ap.add_argument("--kernel", type=int, default=0)
@@ -327,10 +327,17 @@ def bg1_workloads(torch, dist, device, world, rank, args):
             r["cpu_baseline"] = cpu_baseline(bg1.code, cfg, batch, bg1.k, dtype, 5.0)
         out[dtype] = r
         del batch
-    for label, snr in (("f32_early_exit_es_n0_-3dB", -3.0), ("f32_early_exit_es_n0_0dB", 0.0)):
-        r, batch, _ = bg1.run("LNMS", "f32", snr, True, frames, 3, 1, seed=9)
-        out[label] = {k: r[k] for k in ("value", "unit", "ms_per_step", "kernel", "mean_iters", "fer", "ber")}
-        del batch
+    # reduced-precision fast mode: packed half precision, two frames per lane (validated statistically only)
+    r, batch, cfg = bg1.run("LNMS", "f16", 0.0, False, frames, 5, 1, seed=9, with_rooflines=True)
+    r.pop("counters")
+    r["note"] = "reduced precision: half-precision posteriors, 8-bit check magnitudes; no CPU restatement, error rates checked against float32"
+    out["f16x2"] = r
+    del batch
+    for dt in ("f32", "f16"):
+        for label, snr in ((f"{dt}_early_exit_es_n0_-3dB", -3.0), (f"{dt}_early_exit_es_n0_0dB", 0.0)):
+            r, batch, _ = bg1.run("LNMS", dt, snr, True, frames, 3, 1, seed=9)
+            out[label] = {k: r[k] for k in ("value", "unit", "ms_per_step", "kernel", "mean_iters", "fer", "ber")}
+            del batch
     return out
 
 

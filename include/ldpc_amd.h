@@ -73,7 +73,9 @@ extern "C" {
  * compute_dtype only: packed half precision, two frames per lane - a reduced-precision fast mode with
  * no counterpart in the reference (which computes in float64).  Not bit-exact with anything; meant for
  * error-rate sweeps, validated statistically against the float32 kernels.  Served for rule R1 on the
- * small compiled-in codes with float LLRs and posterior_dev = NULL; LDPC_ERR_UNSUPPORTED otherwise.
+ * small compiled-in codes and for LDPC_RULE_LNMS on the compiled-in codes without double-circulant
+ * blocks (half-precision posteriors, check magnitudes kept as eight bits; a posterior of exactly zero
+ * decides 0 there), with float LLRs and posterior_dev = NULL; LDPC_ERR_UNSUPPORTED otherwise.
  */
 #define LDPC_F16 2
 
