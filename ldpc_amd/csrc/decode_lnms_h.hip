@@ -157,22 +157,21 @@ lnms_h_kernel(int max_iters, int early_exit, float scale_f, const float *__restr
             if constexpr (s == 0) return bc * Z + zo;
             else { const int v = zo + s; return bc * Z + (v >= Z ? v - Z : v); }
         };
-        // the pair's channel values of the degree-one variable of block row br: the block column goes into
-        // the scalar base address, the lane part is the frame's 32-bit offset
+        // the pair's channel values of the degree-one variable of block row br: scalar base address of the
+        // group, 32-bit offsets per lane
         auto load_priv_raw = [&](auto br, float &a, float &b) {
             constexpr int e = C::row_ptr[br] + PL::priv_pos(br), bc = C::row_col[e], s = C::row_shift[e];
             unsigned cb = bc * Z * 4;
             asm volatile("" : "+s"(cb));  // formed where it is used: the optimiser would precompute and spill every row's
-            const char *base = lf + cb;
             if constexpr (s == 0) {
-                a = *reinterpret_cast<const float *>(base + o0);
-                b = *reinterpret_cast<const float *>(base + o1);
+                a = *reinterpret_cast<const float *>(lf + (o0 + cb));
+                b = *reinterpret_cast<const float *>(lf + (o1 + cb));
             } else {
                 unsigned zz = (unsigned)z;
                 asm volatile("" : "+v"(zz));  // computed where it is used
-                const unsigned d = (zz + s >= (unsigned)Z ? (unsigned)(s - Z) : (unsigned)s) * 4u;
-                a = *reinterpret_cast<const float *>(base + (o0 + d));
-                b = *reinterpret_cast<const float *>(base + (o1 + d));
+                const unsigned d = (zz + s >= (unsigned)Z ? (unsigned)(s - Z) : (unsigned)s) * 4u + cb;
+                a = *reinterpret_cast<const float *>(lf + (o0 + d));
+                b = *reinterpret_cast<const float *>(lf + (o1 + d));
             }
         };
         auto load_priv = [&](auto br) -> h2 {

@@ -18,7 +18,7 @@ src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(ROOT, "profiles")
 WORKLOADS = {"ccsds_r0_f64": "ccsds512/R0/f64/f32llr", "ccsds_r0_f64_fused": "ccsds512/R0/f64/fused",
              "ccsds_r0_f64_ee": "ccsds512/R0/f64/f32llr/early_exit", "bg1_lnms_f32": "nr_bg1_z384/LNMS/f32/f32llr",
-             "bg1_lnms_f64": "nr_bg1_z384/LNMS/f64/f32llr",
+             "bg1_lnms_f64": "nr_bg1_z384/LNMS/f64/f32llr", "bg1_lnms_f16": "nr_bg1_z384/LNMS/f16/f32llr",
              "bg2_R0_f64": "nr_bg2_z40/R0/f64/f32llr", "bg2_R0_f32": "nr_bg2_z40/R0/f32/f32llr",
              "bg2_R1_f32": "nr_bg2_z40/R1/f32/f32llr", "bg2_R3_f32": "nr_bg2_z40/R3/f32/f32llr"}
 # only the workloads this tag's run covered

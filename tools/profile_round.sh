@@ -23,6 +23,7 @@ echo "stats ccsds done"
 run_stats stats_ccsds_r0_f64_fused --fused --early-exit
 run_stats stats_bg1_lnms_f32 --code nr_bg1_z384 --rule LNMS --dtype f32 --frames 16384
 run_stats stats_bg1_lnms_f64 --code nr_bg1_z384 --rule LNMS --dtype f64 --frames 16384
+run_stats stats_bg1_lnms_f16 --code nr_bg1_z384 --rule LNMS --dtype f16 --frames 16384
 echo "stats bg1 done"
 run_pmc fetch_ccsds_r0_f64 FETCH_SIZE
 run_pmc write_ccsds_r0_f64 WRITE_SIZE
@@ -35,10 +36,13 @@ run_pmc fetch_bg1_lnms_f32 FETCH_SIZE --code nr_bg1_z384 --rule LNMS --dtype f32
 run_pmc write_bg1_lnms_f32 WRITE_SIZE --code nr_bg1_z384 --rule LNMS --dtype f32 --frames 16384
 run_pmc fetch_bg1_lnms_f64 FETCH_SIZE --code nr_bg1_z384 --rule LNMS --dtype f64 --frames 16384
 run_pmc write_bg1_lnms_f64 WRITE_SIZE --code nr_bg1_z384 --rule LNMS --dtype f64 --frames 16384
+run_pmc fetch_bg1_lnms_f16 FETCH_SIZE --code nr_bg1_z384 --rule LNMS --dtype f16 --frames 16384
+run_pmc write_bg1_lnms_f16 WRITE_SIZE --code nr_bg1_z384 --rule LNMS --dtype f16 --frames 16384
 echo "pmc bg1 done"
 SQ="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_ANY"
 run_pmc sq_ccsds_r0_f64 "$SQ"
 run_pmc sq_bg1_lnms_f32 "$SQ" --code nr_bg1_z384 --rule LNMS --dtype f32 --frames 16384
 run_pmc sq_bg1_lnms_f64 "$SQ" --code nr_bg1_z384 --rule LNMS --dtype f64 --frames 16384
+run_pmc sq_bg1_lnms_f16 "$SQ" --code nr_bg1_z384 --rule LNMS --dtype f16 --frames 16384
 echo "sq counters done"
 ls "$OUT"
