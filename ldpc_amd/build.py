@@ -21,7 +21,7 @@ OBJ = os.path.join(CSRC, "obj")
 LIB = os.path.join(HERE, "libldpc_amd.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-         "-I", os.path.join(ROOT, "include"), "-I", CSRC]
+         "-I", os.path.join(ROOT, "include"), "-I", CSRC] + os.environ.get("LDPC_EXTRA_FLAGS", "").split()  # development aid: extra -D switches
 
 #: (object name, source, extra flags)
 # slowest units first: the pool starts them in this order

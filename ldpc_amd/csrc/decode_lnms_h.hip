@@ -38,6 +38,9 @@ namespace ldpc {
 constexpr int kShortRow = 10;  // inputs whose signs fit the first state word
 constexpr unsigned kMagCut = 0x7f807f80u;  // the upper eight magnitude bits of both halves
 constexpr unsigned kMagHalfStep = 0x00400040u;  // half of the lowest kept bit: no carry leaves a half (magnitudes <= 2000)
+#ifndef LDPC_LNMSH_PREFETCH
+#define LDPC_LNMSH_PREFETCH 1
+#endif
 #ifndef LDPC_LNMSH_RESERVE
 #define LDPC_LNMSH_RESERVE 53
 #endif
@@ -225,8 +228,11 @@ lnms_h_kernel(int max_iters, int early_exit, float scale_f, const float *__restr
 
         constexpr int NPL = PL::n_priv_layers();
         constexpr int SYN_FIRST = 2, SYN_EVERY = 6;  // block rows between looks at the outcome of the syndrome test
-        float lp_a = 0.0f, lp_b = 0.0f;  // channel values of the next layer's degree-one variable, requested one layer ahead
-        if constexpr (NPL > 0) load_priv_raw(IC<PL::priv_layer(0)>{}, lp_a, lp_b);
+        // channel values of the degree-one variables of the coming layers, requested PF such layers ahead
+        // (cyclically over the sweeps, hence a divisor of their number)
+        constexpr int PF = NPL == 0 || NPL % LDPC_LNMSH_PREFETCH != 0 ? 1 : LDPC_LNMSH_PREFETCH;
+        float lp_a[PF], lp_b[PF];
+        static_for<0, (NPL == 0 ? 0 : PF)>([&](auto j) { load_priv_raw(IC<PL::priv_layer(j)>{}, lp_a[j], lp_b[j]); });
 
         bool done0 = !act0, done1 = !act1;
         int res_conv0 = 0, res_conv1 = 0;
@@ -315,8 +321,8 @@ lnms_h_kernel(int max_iters, int early_exit, float scale_f, const float *__restr
                     h2 lp = 0u;
                     if constexpr (PP >= 0) {
                         constexpr int j = PL::priv_layer_ord(br);
-                        lp = pack_half2_clamped(lp_a, lp_b, clamp2);
-                        if constexpr (NPL > 1) load_priv_raw(IC<PL::priv_layer((j + 1) % NPL)>{}, lp_a, lp_b);
+                        lp = pack_half2_clamped(lp_a[j % PF], lp_b[j % PF], clamp2);
+                        if constexpr (NPL > PF) load_priv_raw(IC<PL::priv_layer((j + PF) % NPL)>{}, lp_a[j % PF], lp_b[j % PF]);
                     }
                     if (!slot_done) {
                         h2 q[D];
