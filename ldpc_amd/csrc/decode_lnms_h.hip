@@ -22,7 +22,9 @@
 //   W      per frame 16 bits: bit 15 sign parity of the inputs | bit 14 hard decision of the check's
 //          degree-one variable | bits 13-10 position of the smallest input | bits 9-0 input signs
 //          (first edge highest).  Checks of more than ten inputs keep a second word for the signs of
-//          inputs 10... and use five position bits.
+//          inputs 10... and use five position bits; checks of at most seven inputs keep, in place of
+//          the position, one bit per edge "this edge held the smallest magnitude" (bits 13 down), which
+//          saves turning the second pass's outcome into a position and back.
 // Hard decisions are the sign bits of the posteriors (a posterior of exactly +0 decides 0 here).
 // A frame of a pair that converges is written out at once; its partner goes on.
 #include <cstdio>
@@ -36,6 +38,7 @@
 namespace ldpc {
 
 constexpr int kShortRow = 10;  // inputs whose signs fit the first state word
+constexpr int kTinyRow = 7;    // inputs of a check that keeps one "held the minimum" bit per edge instead of a position
 constexpr unsigned kMagCut = 0x7f807f80u;  // the upper eight magnitude bits of both halves
 constexpr unsigned kMagHalfStep = 0x00400040u;  // half of the lowest kept bit: no carry leaves a half (magnitudes <= 2000)
 #ifndef LDPC_LNMSH_PREFETCH
@@ -49,6 +52,7 @@ template <class C>
 struct LnHPlan {
     typedef LnPlan<C> PL;
     static constexpr bool is_long(int br) { return PL::rdeg(br) > kShortRow; }
+    static constexpr bool is_tiny(int br) { return PL::rdeg(br) <= kTinyRow; }
     static constexpr int da(int br) { return is_long(br) ? kShortRow : PL::rdeg(br); }
     static constexpr int words(int br) { return is_long(br) ? 3 : 2; }
     static constexpr bool supported() { return PL::supported() && C::MAX_DC <= 2 * kShortRow; }
@@ -310,11 +314,10 @@ lnms_h_kernel(int max_iters, int early_exit, float scale_f, const float *__restr
                 }
             }
             // ---- one sweep over the layers
-            const bool want_bits = early_exit || t == max_iters - 1;
             const bool slot_done = done0 && done1;
             static_for<0, MB>([&](auto br) {
                 constexpr int e0 = C::row_ptr[br], D = C::row_ptr[br + 1] - e0, PP = PL::priv_pos(br);
-                constexpr bool LONG = HP::is_long(br);
+                constexpr bool LONG = HP::is_long(br), TINY = HP::is_tiny(br);
                 constexpr int DA = HP::da(br), DB = D - DA;
                 if constexpr (D >= 2) {
                     if constexpr (!LY::SINGLE && PL::barrier_before(br)) __syncthreads();
@@ -343,7 +346,10 @@ lnms_h_kernel(int max_iters, int early_exit, float scale_f, const float *__restr
                             }
                         });
                         // position of the previous minimum, counted down edge by edge: zero at its own edge
-                        unsigned cnt = pk_shr<10>(w) & (LONG ? 0x001f001fu : 0x000f000fu);
+                        // (tiny rows: one bit per edge, the current edge's on top)
+                        unsigned cnt;
+                        if constexpr (TINY) cnt = pk_shl<2>(w);
+                        else cnt = pk_shr<10>(w) & (LONG ? 0x001f001fu : 0x000f000fu);
                         const unsigned dba_o = pk_sub_u16(Bo, Ao);
                         // bit 15 of a half of wsa / wsb: sign of the old message on the current edge.  Every edge
                         // shifts it out and the sign of its input in at the bottom: the words end as the new signs.
@@ -356,9 +362,9 @@ lnms_h_kernel(int max_iters, int early_exit, float scale_f, const float *__restr
                             unsigned &ws = (p < DA) ? wsa : wsb;
                             if constexpr (p == PP) {
                                 q[p] = lp;  // a variable of degree one always sends its channel value
-                                hedge_in_given<p == 0>(q[p], cnt, ws, m1, m2, sx, big2);
+                                hedge_in_given<p == 0, TINY>(q[p], cnt, ws, m1, m2, sx, big2);
                             } else {
-                                hedge_in<p == 0>(q[p], cnt, Ao, dba_o, ws, m1, m2, sx, big2);
+                                hedge_in<p == 0, TINY>(q[p], cnt, Ao, dba_o, ws, m1, m2, sx, big2);
                             }
                         });
                         const unsigned px = sx & kSignMask;
@@ -380,22 +386,28 @@ lnms_h_kernel(int max_iters, int early_exit, float scale_f, const float *__restr
                                     lds_put<h2>(off[p], pn);
                                 }
                                 __builtin_amdgcn_sched_barrier(0);  // block, write, block, write
-                            } else if (want_bits) {
+                            } else {  // its hard decisions ride in the state word for the syndrome test and the write-out
                                 privbit = (pn >> 1) & 0x40004000u;
                             }
                         });
-                        // position of the first smallest input, per frame: edge p sits at bit D - 1 - p
-                        unsigned c0, c1;
-                        if constexpr (LONG) {
-                            c0 = ((mina & 0xffffu) << DB) | (minb & 0xffffu);
-                            c1 = ((mina >> 16) << DB) | (minb >> 16);
+                        unsigned wn;
+                        if constexpr (TINY) {
+                            // the bits as they are: edge p at bit 13 - p
+                            wn = (mina << (14 - D)) | wsa | px;
                         } else {
-                            c0 = mina & 0xffffu;
-                            c1 = mina >> 16;
+                            // position of the first smallest input, per frame: edge p sits at bit D - 1 - p
+                            unsigned c0, c1;
+                            if constexpr (LONG) {
+                                c0 = ((mina & 0xffffu) << DB) | (minb & 0xffffu);
+                                c1 = ((mina >> 16) << DB) | (minb >> 16);
+                            } else {
+                                c0 = mina & 0xffffu;
+                                c1 = mina >> 16;
+                            }
+                            const unsigned i0 = (unsigned)__builtin_clz(c0 | 1u) - (unsigned)(32 - D);
+                            const unsigned i1 = (unsigned)__builtin_clz(c1 | 1u) - (unsigned)(32 - D);
+                            wn = wsa | px | (i0 << 10) | (i1 << 26);
                         }
-                        const unsigned i0 = (unsigned)__builtin_clz(c0 | 1u) - (unsigned)(32 - D);
-                        const unsigned i1 = (unsigned)__builtin_clz(c1 | 1u) - (unsigned)(32 - D);
-                        unsigned wn = wsa | px | (i0 << 10) | (i1 << 26);
                         unsigned wxn = 0;
                         if constexpr (LONG) wxn = wsb | px | privbit;
                         else wn |= privbit;
