@@ -52,8 +52,7 @@ __device__ __forceinline__ int spec_r0_checks(const unsigned char *post_b, unsig
         static_for<0, D>([&](auto p) {
             constexpr int bc = C::row_col[e0 + p], s = C::row_shift[e0 + p];
             const T b = *reinterpret_cast<const T *>(post_b + bc * Z * ST + rot_fwd<Z, ST, s>(zb));
-            m2 = SNum<T>::second(m1, m2, b);
-            m1 = SNum<T>::min_abs(m1, b);
+            SNum<T>::template book<p>(m1, m2, b);
             sx ^= SNum<T>::sign_word(b);
             if constexpr (FLOATCHK) fsum += b;
         });
@@ -77,8 +76,16 @@ __device__ __forceinline__ int spec_r0_checks(const unsigned char *post_b, unsig
 
 // FUSED: the channel in front and the error accounting behind run inside the kernel (sweep_fused.h);
 // llr and the result arrays are unused, `sp` describes the channel and the counters.
+// Registers: for the small base graphs (CCSDS) at least three waves per SIMD in double and four in
+// float, as the single-wave workgroups are sized for (a few registers more would silently cost a
+// wave per SIMD); larger graphs take what they need.
 template <class C, typename T, typename TL, int F, bool FUSED = false>
-__global__ void __launch_bounds__((SpecLayout<C, T, F>::THREADS)) LDPC_SPEC_OCC
+__global__ void __launch_bounds__((SpecLayout<C, T, F>::THREADS))
+#if LDPC_SPEC_WAVES > 0
+LDPC_SPEC_OCC
+#else
+__attribute__((amdgpu_waves_per_eu((SpecLayout<C, T, F>::SINGLE && C::EB <= 40 ? (sizeof(T) == 8 ? 3 : 4) : 1), 8)))
+#endif
 spec_r0_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__restrict__ hard_out,
                int *__restrict__ iters_out, uint8_t *__restrict__ conv_out, T *__restrict__ post_out, SweepDev sp)
 {
@@ -199,9 +206,20 @@ spec_r0_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *
                     const T ao = t_abs(own[bc]);
                     T r[D > 0 ? D : 1];
                     unsigned off[D > 0 ? D : 1];
+                    static_for<0, D>([&](auto k) { off[k] = rot_bwd<Z, SP, C::col_shift[k0 + k]>(zp); });
+                    // two circulants in one block: the messages are summed lower check index first
+                    // (ldpc.py:175,188), and which of the two checks that is depends on the lane.  Both lie in
+                    // the same block row, so ordering the two offsets (loop-invariant) orders the messages.
+                    static_for<0, (D > 0 ? D - 1 : 0)>([&](auto k) {
+                        if constexpr (C::col_pair[k0 + k] != 0) {
+                            static_assert(C::col_row[k0 + k] == C::col_row[k0 + k + 1], "a pair shares its block row");
+                            const unsigned a = off[k], b = off[k + 1];
+                            off[k] = min(a, b);
+                            off[k + 1] = max(a, b);
+                        }
+                    });
                     static_for<0, D>([&](auto k) {
-                        constexpr int br = C::col_row[k0 + k], s = C::col_shift[k0 + k];
-                        off[k] = rot_bwd<Z, SP, s>(zp);
+                        constexpr int br = C::col_row[k0 + k];
                         const Pair c = *reinterpret_cast<const Pair *>(cs_b + br * Z * SP + off[k]);
                         // both candidates already carry the check's sign parity; the variable's own sign
                         // is common to all its messages and is applied once, to their sum (negating
@@ -209,16 +227,10 @@ spec_r0_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *
                         // been -0.0 vanishes in the addition of the channel value below)
                         r[k] = ao == t_abs(c.x) ? c.y : c.x;
                     });
-                    static_for<0, (D > 0 ? D - 1 : 0)>([&](auto k) {
-                        if constexpr (C::col_pair[k0 + k] != 0) {  // lower check index first
-                            const bool sw = off[k] > off[k + 1];
-                            const T a = r[k], b = r[k + 1];
-                            r[k] = sw ? b : a;
-                            r[k + 1] = sw ? a : b;
-                        }
-                    });
-                    T s = (T)0;  // ldpc.py:173,188
-                    static_for<0, D>([&](auto k) { s += r[k]; });
+                    // ldpc.py:173,188: the reference starts from 0.0; 0.0 + r differs from r only in the sign
+                    // of a zero, which the addition of the channel value (never -0.0) removes again
+                    T s = D > 0 ? r[0] : (T)0;
+                    static_for<1, (D > 1 ? D : 1)>([&](auto k) { s += r[k]; });
                     own[bc] = g.scale * (SNum<T>::flip_sign(s, so) + L[bc]);  // ldpc.py:196
                     *reinterpret_cast<T *>(post_b + bc * Z * ST + zb) = own[bc];
                 });
@@ -347,8 +359,7 @@ spec_r1_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *
                     static_for<0, D>([&](auto p) {
                         constexpr int kpos = C::row_kpos[e0 + p], s = C::row_shift[e0 + p];
                         const T v = *reinterpret_cast<const T *>(qv_b + kpos * Z * ST + rot_fwd<Z, ST, s>(zb));
-                        m2 = SNum<T>::second(m1, m2, v);
-                        m1 = SNum<T>::min_abs(m1, v);
+                        SNum<T>::template book<p>(m1, m2, v);
                         sx ^= SNum<T>::sign_word(v);
                     });
                     if constexpr (D < 2) { m1 = (T)0; m2 = (T)0; }  // bpsk.py:216

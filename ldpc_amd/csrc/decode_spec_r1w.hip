@@ -104,8 +104,7 @@ spec_r1w_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t 
                                     constexpr int kpos = C::row_kpos[e0 + p], s = C::row_shift[e0 + p], bc = C::row_col[e0 + p];
                                     const T v = *reinterpret_cast<const T *>(qv_b + kpos * Z * ST + rot_fwd<Z, ST, s>(zb));
                                     if (want_syn) par ^= hb_b[bc * Z + rot_fwd<Z, 1, s>(z1)];
-                                    m2 = SNum<T>::second(m1, m2, v);
-                                    m1 = SNum<T>::min_abs(m1, v);
+                                    SNum<T>::template book<p>(m1, m2, v);
                                     sx ^= SNum<T>::sign_word(v);
                                 });
                                 if constexpr (D < 2) { m1 = (T)0; m2 = (T)0; }  // bpsk.py:216
@@ -300,8 +299,7 @@ spec_r1w_slots_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, ui
                                 constexpr int kpos = C::row_kpos[e0 + p], s = C::row_shift[e0 + p], bc = C::row_col[e0 + p];
                                 const T v = *reinterpret_cast<const T *>(qv_b + kpos * Z * ST + rot_fwd<Z, ST, s>(zb));
                                 par ^= hb_b[bc * Z + rot_fwd<Z, 1, s>(z1)];
-                                m2 = SNum<T>::second(m1, m2, v);
-                                m1 = SNum<T>::min_abs(m1, v);
+                                SNum<T>::template book<p>(m1, m2, v);
                                 sx ^= SNum<T>::sign_word(v);
                             });
                             if constexpr (D < 2) { m1 = (T)0; m2 = (T)0; }  // bpsk.py:216
@@ -494,8 +492,7 @@ spec_r0w_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t 
                                 static_for<0, D>([&](auto p) {
                                     constexpr int bc = C::row_col[e0 + p], s = C::row_shift[e0 + p];
                                     const T b = *reinterpret_cast<const T *>(post_b + bc * Z * ST + rot_fwd<Z, ST, s>(zb));
-                                    m2 = SNum<T>::second(m1, m2, b);
-                                    m1 = SNum<T>::min_abs(m1, b);
+                                    SNum<T>::template book<p>(m1, m2, b);
                                     sx ^= SNum<T>::sign_word(b);
                                     if constexpr (FC) fsum += b;
                                 });

@@ -32,6 +32,17 @@ template <> struct SNum<float> {
     __device__ static __forceinline__ float second(float m1, float m2, float b) {  // m1 <= m2
         float d; asm("v_med3_f32 %0, %1, %2, |%3|" : "=v"(d) : "v"(m1), "v"(m2), "v"(b)); return d;
     }
+    __device__ static __forceinline__ float max_abs(float m, float b) {
+        float d; asm("v_max_f32 %0, %1, |%2|" : "=v"(d) : "v"(m), "v"(b)); return d;
+    }
+    // book |b| of a check's P-th input in the running smallest / second smallest (m1 <= m2, both +infinity
+    // before the first input): the first two inputs need one and two instructions instead of three
+    template <int P>
+    __device__ static __forceinline__ void book(float &m1, float &m2, float b) {
+        if constexpr (P == 0) { m1 = __builtin_fabsf(b); }
+        else if constexpr (P == 1) { m2 = max_abs(m1, b); m1 = min_abs(m1, b); }
+        else { m2 = second(m1, m2, b); m1 = min_abs(m1, b); }
+    }
     __device__ static __forceinline__ Pair make(float a, float b) { return make_float2(a, b); }
     // mag = |q| == m1 ? b : a, and the outcome of the comparison is shifted into `bits` from the
     // right (carry-in of an add), so that no lane mask and no constant has to be kept in registers
@@ -106,6 +117,15 @@ template <> struct SNum<double> {
         asm("v_max_f64 %0, %1, |%2|" : "=v"(t) : "v"(m1), "v"(b));
         asm("v_min_f64 %0, %1, %2" : "=v"(d) : "v"(m2), "v"(t));
         return d;
+    }
+    __device__ static __forceinline__ double max_abs(double m, double b) {
+        double d; asm("v_max_f64 %0, %1, |%2|" : "=v"(d) : "v"(m), "v"(b)); return d;
+    }
+    template <int P>
+    __device__ static __forceinline__ void book(double &m1, double &m2, double b) {
+        if constexpr (P == 0) { m1 = __builtin_fabs(b); }
+        else if constexpr (P == 1) { m2 = max_abs(m1, b); m1 = min_abs(m1, b); }
+        else { m2 = second(m1, m2, b); m1 = min_abs(m1, b); }
     }
     __device__ static __forceinline__ Pair make(double a, double b) { return make_double2(a, b); }
     __device__ static __forceinline__ double pick_min(double q, double m1, double a, double b, unsigned &bits) {
