@@ -145,12 +145,20 @@ lnms_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__r
             if constexpr (s == 0) return bc * Z + zo;
             else { const int v = zo + s; return bc * Z + (v >= Z ? v - Z : v); }
         };
+        // scalar base address of the group, 32-bit byte offset per lane; the block column's share of the
+        // offset is formed where it is used (hoisted, every row's address would be precomputed and spilled)
+        const unsigned fob = fo * (unsigned)sizeof(TL);
         auto load_priv = [&](auto br) -> T {
             constexpr int e = C::row_ptr[br] + PL::priv_pos(br), bc = C::row_col[e], s = C::row_shift[e];
-            unsigned o = fo;
-            asm volatile("" : "+v"(o));  // one address per block row, computed where it is used
-            if constexpr (s != 0) o += (unsigned)z + s >= (unsigned)Z ? (unsigned)(s - Z) : (unsigned)s;
-            return (T)lf[o + (unsigned)(bc * Z)] + (T)0;
+            unsigned cb = bc * Z * (int)sizeof(TL);
+            asm volatile("" : "+s"(cb));
+            unsigned o = fob + cb;
+            if constexpr (s != 0) {
+                unsigned zz = (unsigned)z;
+                asm volatile("" : "+v"(zz));
+                o += (zz + s >= (unsigned)Z ? (unsigned)(s - Z) : (unsigned)s) * (unsigned)sizeof(TL);
+            }
+            return (T)*reinterpret_cast<const TL *>(reinterpret_cast<const char *>(lf) + o) + (T)0;
         };
         // Bit 30 of W holds the hard decision of the layer's private variable whenever a syndrome
         // test may follow (early exit: always; else after the last sweep), so that the test needs
