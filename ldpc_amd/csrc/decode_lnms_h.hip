@@ -328,7 +328,7 @@ lnms_h_kernel(int max_iters, int early_exit, float scale_f, const float *__restr
                         if constexpr (NPL > PF) load_priv_raw(IC<PL::priv_layer((j + PF) % NPL)>{}, lp_a[j % PF], lp_b[j % PF]);
                     }
                     if (!slot_done) {
-                        h2 q[D];
+                        h2 q[D], aq[LONG ? 1 : D];  // the inputs and (short rows) their magnitudes
                         unsigned off[D];
                         unsigned ab, w, wx;
                         load_state(br, ab, w, wx);
@@ -362,9 +362,9 @@ lnms_h_kernel(int max_iters, int early_exit, float scale_f, const float *__restr
                             unsigned &ws = (p < DA) ? wsa : wsb;
                             if constexpr (p == PP) {
                                 q[p] = lp;  // a variable of degree one always sends its channel value
-                                hedge_in_given<p == 0, TINY>(q[p], cnt, ws, m1, m2, sx, big2);
+                                hedge_in_given<p == 0, TINY>(q[p], aq[LONG ? 0 : (int)p], cnt, ws, m1, m2, sx, big2);
                             } else {
-                                hedge_in<p == 0, TINY>(q[p], cnt, Ao, dba_o, ws, m1, m2, sx, big2);
+                                hedge_in<p == 0, TINY>(q[p], aq[LONG ? 0 : (int)p], cnt, Ao, dba_o, ws, m1, m2, sx, big2);
                             }
                         });
                         const unsigned px = sx & kSignMask;
@@ -373,11 +373,14 @@ lnms_h_kernel(int max_iters, int early_exit, float scale_f, const float *__restr
                         const h2 Bn = (pk_min(pk_mul(m2, scale2), clamp2) + kMagHalfStep) & kMagCut;
                         const unsigned Anp = An | px;  // the parity of the inputs folded into the new messages
                         const unsigned dba_n = pk_sub_u16(Bn, An);
+                        const unsigned m1p1 = m1 + 0x00010001u;  // bit patterns: no carry leaves a half
                         unsigned mina = 0, minb = 0;   // per edge: does it hold the smallest magnitude?
                         unsigned privbit = 0;
                         static_for<0, D>([&](auto p) {
                             unsigned &mn = (p < DA) ? mina : minb;
-                            const h2 pn = hedge_out(q[p], m1, Anp, dba_n, mn);  // the variable's new posterior
+                            h2 pn;  // the variable's new posterior
+                            if constexpr (LONG) pn = hedge_out_nomag(q[p], m1, Anp, dba_n, mn);
+                            else pn = hedge_out(q[p], aq[p], m1p1, Anp, dba_n, mn);
                             if constexpr (p != PP) {
                                 if constexpr (LONG) {  // a long row's addresses are formed again: keeping them costs registers
                                     constexpr int bc = C::row_col[e0 + p], s = C::row_shift[e0 + p];

@@ -113,20 +113,20 @@ __device__ __forceinline__ unsigned and_xor(unsigned a, unsigned b, unsigned mas
 #define LDPC_HEDGE_SEL_HOT "v_pk_lshrrev_b16 %[t], 15, %[c] op_sel_hi:[0,1]\n\tv_pk_add_u16 %[c], %[c], %[c]\n\t"
 #define LDPC_HEDGE_OLD "v_pk_mad_u16 %[t], %[t], %[dba], %[a]\n\tv_and_or_b32 %[t], %[ws], %[S], %[t]\n\t" \
                        "v_pk_add_f16 %[q], %[q], %[t] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-#define LDPC_HEDGE_BOOK "v_and_b32 %[t], 0x7fff7fff, %[q]\n\tv_pk_max_f16 %[u], %[m1], %[t]\n\tv_pk_min_f16 %[m2], %[m2], %[u]\n\t" \
-                        "v_pk_min_f16 %[m1], %[m1], %[t]\n\tv_pk_lshrrev_b16 %[t], 15, %[q] op_sel_hi:[0,1]\n\t"                   \
+#define LDPC_HEDGE_BOOK "v_and_b32 %[aq], 0x7fff7fff, %[q]\n\tv_pk_max_f16 %[u], %[m1], %[aq]\n\tv_pk_min_f16 %[m2], %[m2], %[u]\n\t" \
+                        "v_pk_min_f16 %[m1], %[m1], %[aq]\n\tv_pk_lshrrev_b16 %[t], 15, %[q] op_sel_hi:[0,1]\n\t"                  \
                         "v_pk_mad_u16 %[ws], %[ws], 2, %[t] op_sel_hi:[1,0,1]\n\tv_xor_b32 %[sx], %[sx], %[q]"
-#define LDPC_HEDGE_BOOK1 "v_and_b32 %[m1], 0x7fff7fff, %[q]\n\tv_mov_b32 %[m2], %[big]\n\tv_pk_lshrrev_b16 %[t], 15, %[q] op_sel_hi:[0,1]\n\t" \
+#define LDPC_HEDGE_BOOK1 "v_and_b32 %[aq], 0x7fff7fff, %[q]\n\tv_mov_b32 %[m1], %[aq]\n\tv_mov_b32 %[m2], %[big]\n\tv_pk_lshrrev_b16 %[t], 15, %[q] op_sel_hi:[0,1]\n\t" \
                          "v_pk_mad_u16 %[ws], %[ws], 2, %[t] op_sel_hi:[1,0,1]\n\tv_mov_b32 %[sx], %[q]"
 // HOT: c is not a counter but one bit per edge ("this edge held the minimum"), the current edge's in
 // the top bit of each half, shifted up edge by edge.
 template <bool FIRST, bool HOT>
-__device__ __forceinline__ void hedge_in(h2 &q, unsigned &c, h2 a, unsigned dba, unsigned &ws, h2 &m1, h2 &m2, unsigned &sx, h2 big)
+__device__ __forceinline__ void hedge_in(h2 &q, h2 &aq, unsigned &c, h2 a, unsigned dba, unsigned &ws, h2 &m1, h2 &m2, unsigned &sx, h2 big)
 {
     unsigned t, u;
-#define LDPC_HEDGE_FIRST_OPS : [q] "+v"(q), [c] "+v"(c), [t] "=&v"(t), [ws] "+v"(ws), [m1] "=&v"(m1), [m2] "=&v"(m2), [sx] "=&v"(sx) \
+#define LDPC_HEDGE_FIRST_OPS : [q] "+v"(q), [aq] "=&v"(aq), [c] "+v"(c), [t] "=&v"(t), [ws] "+v"(ws), [m1] "=&v"(m1), [m2] "=&v"(m2), [sx] "=&v"(sx) \
                              : [a] "v"(a), [dba] "v"(dba), [S] "s"(kSignMask), [big] "v"(big)
-#define LDPC_HEDGE_NEXT_OPS : [q] "+v"(q), [c] "+v"(c), [t] "=&v"(t), [u] "=&v"(u), [ws] "+v"(ws), [m1] "+v"(m1), [m2] "+v"(m2), [sx] "+v"(sx) \
+#define LDPC_HEDGE_NEXT_OPS : [q] "+v"(q), [aq] "=&v"(aq), [c] "+v"(c), [t] "=&v"(t), [u] "=&v"(u), [ws] "+v"(ws), [m1] "+v"(m1), [m2] "+v"(m2), [sx] "+v"(sx) \
                             : [a] "v"(a), [dba] "v"(dba), [S] "s"(kSignMask)
     if constexpr (FIRST && HOT) asm(LDPC_HEDGE_SEL_HOT LDPC_HEDGE_OLD LDPC_HEDGE_BOOK1 LDPC_HEDGE_FIRST_OPS);
     else if constexpr (FIRST) asm(LDPC_HEDGE_SEL_CNT LDPC_HEDGE_OLD LDPC_HEDGE_BOOK1 LDPC_HEDGE_FIRST_OPS);
@@ -137,13 +137,13 @@ __device__ __forceinline__ void hedge_in(h2 &q, unsigned &c, h2 a, unsigned dba,
 }
 // the same for an edge whose input is given (no previous message to take off); the counter still moves on
 template <bool FIRST, bool HOT>
-__device__ __forceinline__ void hedge_in_given(h2 q, unsigned &c, unsigned &ws, h2 &m1, h2 &m2, unsigned &sx, h2 big)
+__device__ __forceinline__ void hedge_in_given(h2 q, h2 &aq, unsigned &c, unsigned &ws, h2 &m1, h2 &m2, unsigned &sx, h2 big)
 {
     unsigned t, u;
 #define LDPC_HEDGE_STEP_CNT "v_pk_sub_u16 %[c], %[c], 1 op_sel_hi:[1,0]\n\t"
 #define LDPC_HEDGE_STEP_HOT "v_pk_add_u16 %[c], %[c], %[c]\n\t"
-#define LDPC_HEDGE_FIRST_OPS : [c] "+v"(c), [t] "=&v"(t), [ws] "+v"(ws), [m1] "=&v"(m1), [m2] "=&v"(m2), [sx] "=&v"(sx) : [q] "v"(q), [big] "v"(big)
-#define LDPC_HEDGE_NEXT_OPS : [c] "+v"(c), [t] "=&v"(t), [u] "=&v"(u), [ws] "+v"(ws), [m1] "+v"(m1), [m2] "+v"(m2), [sx] "+v"(sx) : [q] "v"(q)
+#define LDPC_HEDGE_FIRST_OPS : [aq] "=&v"(aq), [c] "+v"(c), [t] "=&v"(t), [ws] "+v"(ws), [m1] "=&v"(m1), [m2] "=&v"(m2), [sx] "=&v"(sx) : [q] "v"(q), [big] "v"(big)
+#define LDPC_HEDGE_NEXT_OPS : [aq] "=&v"(aq), [c] "+v"(c), [t] "=&v"(t), [u] "=&v"(u), [ws] "+v"(ws), [m1] "+v"(m1), [m2] "+v"(m2), [sx] "+v"(sx) : [q] "v"(q)
     if constexpr (FIRST && HOT) asm(LDPC_HEDGE_STEP_HOT LDPC_HEDGE_BOOK1 LDPC_HEDGE_FIRST_OPS);
     else if constexpr (FIRST) asm(LDPC_HEDGE_STEP_CNT LDPC_HEDGE_BOOK1 LDPC_HEDGE_FIRST_OPS);
     else if constexpr (HOT) asm(LDPC_HEDGE_STEP_HOT LDPC_HEDGE_BOOK LDPC_HEDGE_NEXT_OPS);
@@ -158,9 +158,23 @@ __device__ __forceinline__ void hedge_in_given(h2 q, unsigned &c, unsigned &ws, 
 #undef LDPC_HEDGE_OLD
 #undef LDPC_HEDGE_BOOK
 #undef LDPC_HEDGE_BOOK1
-// Second pass of an edge: e = 1 where |q| == m1; new message magnitude An + e (Bn - An) with the
-// parity of the inputs in its sign bits (anp), times sign(q); e funnelled into mn; returns q + message.
-__device__ __forceinline__ h2 hedge_out(h2 q, h2 m1, unsigned anp, unsigned dba, unsigned &mn)
+// Second pass of an edge: e = 1 where |q| == m1, as the saturating difference (m1 + 1) - |q| of the
+// bit patterns (|q| >= m1); new message magnitude An + e (Bn - An) with the parity of the inputs in
+// its sign bits (anp), times sign(q); e funnelled into mn; returns q + message.
+__device__ __forceinline__ h2 hedge_out(h2 q, h2 aq, unsigned m1p1, unsigned anp, unsigned dba, unsigned &mn)
+{
+    unsigned t;
+    h2 out;
+    asm("v_pk_sub_u16 %[t], %[m1p1], %[aq] clamp\n\t"
+        "v_pk_mad_u16 %[mn], %[mn], 2, %[t] op_sel_hi:[1,0,1]\n\tv_pk_mad_u16 %[t], %[t], %[dba], %[anp]\n\t"
+        "v_bitop3_b32 %[t], %[q], %[t], %[S] bitop3:0x6c\n\tv_pk_add_f16 %[out], %[q], %[t]"
+        : [out] "=v"(out), [t] "=&v"(t), [mn] "+v"(mn)
+        : [q] "v"(q), [aq] "v"(aq), [m1p1] "v"(m1p1), [anp] "v"(anp), [dba] "v"(dba), [S] "s"(kSignMask));
+    return out;
+}
+
+// the same without the magnitude at hand: |q| xor m1 is formed first (one instruction more, one register less)
+__device__ __forceinline__ h2 hedge_out_nomag(h2 q, h2 m1, unsigned anp, unsigned dba, unsigned &mn)
 {
     unsigned t;
     h2 out;
