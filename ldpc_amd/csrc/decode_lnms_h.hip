@@ -41,6 +41,12 @@ constexpr int kShortRow = 10;  // inputs whose signs fit the first state word
 constexpr int kTinyRow = 7;    // inputs of a check that keeps one "held the minimum" bit per edge instead of a position
 constexpr unsigned kMagCut = 0x7f807f80u;  // the upper eight magnitude bits of both halves
 constexpr unsigned kMagHalfStep = 0x00400040u;  // half of the lowest kept bit: no carry leaves a half (magnitudes <= 2000)
+#ifndef LDPC_LNMSH_DOUBLE_SLOTS
+#define LDPC_LNMSH_DOUBLE_SLOTS 1
+#endif
+#ifndef LDPC_LNMSH_WPE
+#define LDPC_LNMSH_WPE 0
+#endif
 #ifndef LDPC_LNMSH_PREFETCH
 #define LDPC_LNMSH_PREFETCH 1
 #endif
@@ -442,7 +448,7 @@ template <class C, int F>
 struct LnHConfig {
     typedef LnHPlan<C> HP;
     static constexpr int WAVES = ((F * C::Z + 63) / 64);
-    static constexpr int WPE = WAVES >= 4 ? (WAVES + 3) / 4 : 3;
+    static constexpr int WPE = LDPC_LNMSH_WPE > 0 ? LDPC_LNMSH_WPE : WAVES >= 4 ? (WAVES + 3) / 4 : 3;
     static constexpr int VGPRS = WPE <= 2 ? 256 : (512 / WPE) / 8 * 8;
     static constexpr int STATE_REGS = VGPRS - LDPC_LNMSH_RESERVE > 180 ? 180 : VGPRS - LDPC_LNMSH_RESERVE;
     static constexpr int rl()
@@ -460,7 +466,7 @@ struct LnHConfig {
 template <class C, int F>
 struct LnHSlots {
     static constexpr int W1 = (F * C::Z + 63) / 64, W2 = (2 * F * C::Z + 63) / 64;
-    static constexpr bool DOUBLE = W1 >= 4 && W1 % 4 != 0 && W2 % 4 == 0 && LnHConfig<C, 2 * F>::OK;
+    static constexpr bool DOUBLE = LDPC_LNMSH_DOUBLE_SLOTS && W1 >= 4 && W1 % 4 != 0 && W2 % 4 == 0 && LnHConfig<C, 2 * F>::OK;
     static constexpr int value = DOUBLE ? 2 * F : F;
 };
 
