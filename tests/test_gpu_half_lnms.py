@@ -14,6 +14,14 @@ from ldpc_amd import _lib, codes, config
 
 pytestmark = pytest.mark.gpu
 
+
+def clopper_pearson(k, n, conf=0.999):
+    from scipy.stats import beta
+    a = 1 - conf
+    lo = 0.0 if k == 0 else beta.ppf(a / 2, k, n - k + 1)
+    hi = 1.0 if k == n else beta.ppf(1 - a / 2, k + 1, n - k)
+    return lo, hi
+
 CASES = [("nr_bg1_z384", 1 << 13, [-4.0, -3.75, -3.0]),
          ("nr_bg2_z40", 1 << 16, [-6.0, -5.0, -3.0]),
          ("nr_bg2_z40_r1400", 1 << 16, [-5.0, -4.5, -3.0]),
@@ -97,3 +105,28 @@ def test_half_precision_layered_edges():
     # double-circulant blocks (CCSDS) have no layered kernel in any arithmetic
     with pytest.raises(_lib.LdpcError):
         Decoder(codes.load_packaged("ccsds512")).decode(np.zeros((2, 512), np.float32), cfg, compute_dtype=np.float16)
+
+
+@pytest.mark.parametrize("name,snrs", [("wifi648", [-1.5, -1.0, -0.5, 0.0]), ("nr_bg2_z40", [-6.5, -6.0, -5.5, -5.0])])
+def test_half_precision_layered_anchored_to_reference_pinned_flooding_rule(name, snrs):
+    """The same anchor as the float layered kernel has (tests/test_gpu_ber.py), applied to the packed
+    half-precision mode directly: on the reference's own matrices, same frames, ten sweeps in packed
+    half precision are never worse than ten iterations of the reference-pinned flooding rule R1
+    (bpsk.py:154-260, float64) and lie between R1 at twenty iterations and 1.8 times that."""
+    import torch
+    from ldpc_amd import sweep
+    from ldpc_amd.decoder import Decoder
+    code = codes.load_packaged(name)
+    G = codes.load_packaged_generator(name) if name == "wifi648" else None
+    dev = torch.device("cuda", 0)
+    dec = Decoder(code)
+    frames = 1 << 17
+    run = lambda cfg, dt: sweep.ber_sweep(code, G, cfg, snrs, frames, dev, dt, seed=17, dec=dec, fused=False)
+    r10, r20 = run(config.R1.with_(max_iters=10), np.float64), run(config.R1.with_(max_iters=20), np.float64)
+    h10 = run(config.LNMS.with_(max_iters=10), np.float16)
+    for a10, a20, b10 in zip(r10, r20, h10):
+        lo20, hi20 = clopper_pearson(a20["not_converged"], frames)
+        assert b10["frames"] == frames
+        assert b10["not_converged"] <= a10["not_converged"], (name, a10["es_n0_db"])
+        assert 0.9 * lo20 <= b10["fer"] <= 1.8 * hi20, (name, a10["es_n0_db"], b10["fer"], lo20, hi20)
+        assert b10["ber"] <= a10["ber"] and b10["ber"] <= 1.8 * a20["ber"] + 1e-6
