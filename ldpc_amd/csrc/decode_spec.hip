@@ -38,11 +38,28 @@ struct SpecLayout {
 // ------------------------------------------------------------------------------------------ R0
 // check-node phase of one thread: every block row in turn.  Returns 1 if any of its checks fails
 // (FLOATCHK: the iteration-0 test of ldpc.py:158,165 on the raw LLR sums instead of the parity).
+//
+// Edges of shift 0 connect check (br, z) with variable (bc, z): both belong to the same lane, so
+// where the check states of a lane fit registers (LOCAL, base graphs of at most four block rows)
+// such an edge's posterior comes from the lane's own register and its check state goes back the
+// same way (`cl`), and only the rotated edges go through LDS.  The values are the same either way.
+template <class C>
+constexpr bool spec_local_edges()
+{
+#ifdef LDPC_NO_LOCAL_EDGES
+    return false;
+#else
+    return C::MB <= 4;
+#endif
+}
+
 template <class C, typename T, bool FLOATCHK>
-__device__ __forceinline__ int spec_r0_checks(const unsigned char *post_b, unsigned char *cs_b, unsigned zb, unsigned zp)
+__device__ __forceinline__ int spec_r0_checks(const unsigned char *post_b, unsigned char *cs_b, unsigned zb, unsigned zp,
+                                              const T (&own)[C::NB], typename SNum<T>::Pair (&cl)[spec_local_edges<C>() ? C::MB : 1])
 {
     typedef typename SNum<T>::Pair Pair;
     constexpr int Z = C::Z, MB = C::MB, ST = sizeof(T), SP = 2 * sizeof(T);
+    constexpr bool LOCAL = spec_local_edges<C>();
     int bad = 0;
     static_for<0, MB>([&](auto br) {
         constexpr int e0 = C::row_ptr[br], D = C::row_ptr[br + 1] - e0;
@@ -51,14 +68,17 @@ __device__ __forceinline__ int spec_r0_checks(const unsigned char *post_b, unsig
         T fsum = (T)0;
         static_for<0, D>([&](auto p) {
             constexpr int bc = C::row_col[e0 + p], s = C::row_shift[e0 + p];
-            const T b = *reinterpret_cast<const T *>(post_b + bc * Z * ST + rot_fwd<Z, ST, s>(zb));
+            T b;
+            if constexpr (LOCAL && s == 0) b = own[bc];
+            else b = *reinterpret_cast<const T *>(post_b + bc * Z * ST + rot_fwd<Z, ST, s>(zb));
             SNum<T>::template book<p>(m1, m2, b);
             sx ^= SNum<T>::sign_word(b);
             if constexpr (FLOATCHK) fsum += b;
         });
         if constexpr (D < 2) { m1 = (T)0; m2 = (T)0; }  // ldpc.py:178
-        *reinterpret_cast<Pair *>(cs_b + br * Z * SP + zp) =
-            SNum<T>::make(SNum<T>::with_sign(m1, sx), SNum<T>::with_sign(m2, sx));
+        const Pair cst = SNum<T>::make(SNum<T>::with_sign(m1, sx), SNum<T>::with_sign(m2, sx));
+        *reinterpret_cast<Pair *>(cs_b + br * Z * SP + zp) = cst;
+        if constexpr (LOCAL) cl[br] = cst;
         if constexpr (FLOATCHK) bad |= !(t_fmod(fsum, (T)2) == (T)0);
         else bad |= (int)(((unsigned)D ^ (sx >> 31)) & 1u);  // parity of the hard bits 1 - signbit
     });
@@ -93,6 +113,12 @@ spec_r0_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *
     typedef typename SNum<T>::Pair Pair;
     constexpr int Z = C::Z, NB = C::NB, MB = C::MB, ST = sizeof(T), SP = 2 * sizeof(T);
     constexpr int n = NB * Z;
+    constexpr bool LOCAL = spec_local_edges<C>();
+#ifdef LDPC_NO_LOCAL_SWAP
+    constexpr bool LOCAL_SWAP = false;
+#else
+    constexpr bool LOCAL_SWAP = LOCAL;
+#endif
     extern __shared__ __align__(16) unsigned char smem[];
 
     const int tid = threadIdx.x;
@@ -167,14 +193,15 @@ spec_r0_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *
         bool done = !active;
         int t = 0;
         int final_bad = 0;
+        Pair cl[LOCAL ? MB : 1];  // check states of this lane's own checks (spec_r0_checks)
         for (; t <= g.max_iters; ++t) {
             // the pass at t == max_iters only exists in fixed-work mode (final syndrome)
             if (t == g.max_iters && g.early_exit) break;
             const bool float_check = t == 0 && g.float_syndrome0 && g.early_exit;
             int bad = 0;
             if (!done) {
-                bad = float_check ? spec_r0_checks<C, T, true>(post_b, cs_b, zb, zp)
-                                  : spec_r0_checks<C, T, false>(post_b, cs_b, zb, zp);
+                bad = float_check ? spec_r0_checks<C, T, true>(post_b, cs_b, zb, zp, own, cl)
+                                  : spec_r0_checks<C, T, false>(post_b, cs_b, zb, zp, own, cl);
             }
             // ---- does every check of my slot hold?
             bool slot_ok;
@@ -210,23 +237,46 @@ spec_r0_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *
                     // two circulants in one block: the messages are summed lower check index first
                     // (ldpc.py:175,188), and which of the two checks that is depends on the lane.  Both lie in
                     // the same block row, so ordering the two offsets (loop-invariant) orders the messages.
-                    static_for<0, (D > 0 ? D - 1 : 0)>([&](auto k) {
+                    // (the first two messages of a sum commute: a pair there needs no ordering)
+                    // With LOCAL_SWAP a pair one of whose circulants has shift 0 takes that check state from
+                    // the lane's registers and puts the two MESSAGES in order instead (a loop-invariant lane
+                    // mask: the lane's own check comes first where its offset is the smaller one).
+                    static_for<1, (D > 1 ? D - 1 : 1)>([&](auto k) {
                         if constexpr (C::col_pair[k0 + k] != 0) {
                             static_assert(C::col_row[k0 + k] == C::col_row[k0 + k + 1], "a pair shares its block row");
-                            const unsigned a = off[k], b = off[k + 1];
-                            off[k] = min(a, b);
-                            off[k + 1] = max(a, b);
+                            constexpr bool has_local = LOCAL_SWAP && (C::col_shift[k0 + k] == 0 || C::col_shift[k0 + k + 1] == 0);
+                            if constexpr (!has_local) {
+                                const unsigned a = off[k], b = off[k + 1];
+                                off[k] = min(a, b);
+                                off[k + 1] = max(a, b);
+                            }
                         }
                     });
                     static_for<0, D>([&](auto k) {
                         constexpr int br = C::col_row[k0 + k];
-                        const Pair c = *reinterpret_cast<const Pair *>(cs_b + br * Z * SP + off[k]);
+                        // a pair whose messages are not the first two of the sum has to be put in order
+                        constexpr bool ordered = k > 0 && (C::col_pair[k0 + k] != 0 || (k > 1 && C::col_pair[k0 + (k > 1 ? k - 1 : 0)] != 0));
+                        Pair c;
+                        if constexpr (LOCAL && C::col_shift[k0 + k] == 0 && (!ordered || LOCAL_SWAP)) c = cl[br];
+                        else c = *reinterpret_cast<const Pair *>(cs_b + br * Z * SP + off[k]);
                         // both candidates already carry the check's sign parity; the variable's own sign
                         // is common to all its messages and is applied once, to their sum (negating
                         // every term of a sum negates the sum exactly; a sum of +0.0 that would have
                         // been -0.0 vanishes in the addition of the channel value below)
                         r[k] = ao == t_abs(c.x) ? c.y : c.x;
                     });
+                    if constexpr (LOCAL_SWAP) {
+                        static_for<1, (D > 1 ? D - 1 : 1)>([&](auto k) {
+                            if constexpr (C::col_pair[k0 + k] != 0 && (C::col_shift[k0 + k] == 0 || C::col_shift[k0 + k + 1] == 0)) {
+                                constexpr bool local_is_first = C::col_shift[k0 + k] == 0;
+                                const bool own_first = zp < (local_is_first ? off[k + 1] : off[k]);
+                                const bool swap = own_first != local_is_first;
+                                const T a = r[k], b = r[k + 1];
+                                r[k] = swap ? b : a;
+                                r[k + 1] = swap ? a : b;
+                            }
+                        });
+                    }
                     // ldpc.py:173,188: the reference starts from 0.0; 0.0 + r differs from r only in the sign
                     // of a zero, which the addition of the channel value (never -0.0) removes again
                     T s = D > 0 ? r[0] : (T)0;
@@ -277,6 +327,9 @@ spec_r1_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *
     static_assert(LY::THREADS == 64, "single-wave workgroups only");
     constexpr int Z = C::Z, NB = C::NB, MB = C::MB, EB = C::EB, ST = sizeof(T), SP = 2 * sizeof(T);
     constexpr int n = NB * Z;
+    // edges of shift 0 stay inside the lane (see spec_r0_checks): their message and their check state
+    // are never written to LDS
+    constexpr bool LOCAL = spec_local_edges<C>() && LY::QREG;
     extern __shared__ __align__(16) unsigned char smem[];
 
     const int tid = threadIdx.x;
@@ -321,7 +374,9 @@ spec_r1_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *
             hm[bc] = __ballot(!(l > (T)0));
             static_for<0, D>([&](auto k) {  // bpsk.py:170-177
                 if constexpr (LY::QREG) q[k0 + k] = l;
-                if (lane_on) *reinterpret_cast<T *>(qv_b + (k0 + k) * Z * ST + zb) = l;  // idle lanes alias lane 0
+                if constexpr (!(LOCAL && C::col_shift[k0 + k] == 0)) {
+                    if (lane_on) *reinterpret_cast<T *>(qv_b + (k0 + k) * Z * ST + zb) = l;  // idle lanes alias lane 0
+                }
             });
         });
         if constexpr (PREFETCH) {
@@ -344,6 +399,7 @@ spec_r1_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *
 
         bool done = !active;
         int t = 0;
+        Pair cl[LOCAL ? MB : 1];  // check states of this lane's own checks
         for (; t < g.max_iters; ++t) {
             if (g.early_exit) {  // bpsk.py:205-209
                 const bool ok = r1_slot_ok<C, F>(hm, slot_mask);
@@ -358,13 +414,16 @@ spec_r1_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *
                     unsigned sx = 0;
                     static_for<0, D>([&](auto p) {
                         constexpr int kpos = C::row_kpos[e0 + p], s = C::row_shift[e0 + p];
-                        const T v = *reinterpret_cast<const T *>(qv_b + kpos * Z * ST + rot_fwd<Z, ST, s>(zb));
+                        T v;
+                        if constexpr (LOCAL && s == 0) v = q[kpos];
+                        else v = *reinterpret_cast<const T *>(qv_b + kpos * Z * ST + rot_fwd<Z, ST, s>(zb));
                         SNum<T>::template book<p>(m1, m2, v);
                         sx ^= SNum<T>::sign_word(v);
                     });
                     if constexpr (D < 2) { m1 = (T)0; m2 = (T)0; }  // bpsk.py:216
-                    *reinterpret_cast<Pair *>(cs_b + br * Z * SP + zp) =
-                        SNum<T>::make(SNum<T>::with_sign(m1, sx), SNum<T>::with_sign(m2, sx));
+                    const Pair cst = SNum<T>::make(SNum<T>::with_sign(m1, sx), SNum<T>::with_sign(m2, sx));
+                    *reinterpret_cast<Pair *>(cs_b + br * Z * SP + zp) = cst;
+                    if constexpr (LOCAL) cl[br] = cst;
                 });
                 // ---- variable nodes (bpsk.py:235-247)
                 static_for<0, NB>([&](auto bc) {
@@ -377,7 +436,9 @@ spec_r1_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *
                         if constexpr (LY::QREG) qo = q[k0 + k];
                         else qo = *reinterpret_cast<const T *>(qv_b + (k0 + k) * Z * ST + zb);
                         off[k] = rot_bwd<Z, SP, s>(zp);
-                        const Pair c = *reinterpret_cast<const Pair *>(cs_b + br * Z * SP + off[k]);
+                        Pair c;
+                        if constexpr (LOCAL && s == 0) c = cl[br];
+                        else c = *reinterpret_cast<const Pair *>(cs_b + br * Z * SP + off[k]);
                         const T sel = t_abs(qo) == t_abs(c.x) ? c.y : c.x;
                         // sel carries the sign parity of the check in its sign bit
                         const T mag = OMS ? SNum<T>::flip_sign(oms_magnitude(t_abs(sel), g.scale, g.offset),
@@ -410,7 +471,8 @@ spec_r1_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *
                     });
                     static_for<0, D>([&](auto k) {
                         if constexpr (LY::QREG) q[k0 + k] = qn[k];
-                        *reinterpret_cast<T *>(qv_b + (k0 + k) * Z * ST + zb) = qn[k];
+                        if constexpr (!(LOCAL && C::col_shift[k0 + k] == 0))
+                            *reinterpret_cast<T *>(qv_b + (k0 + k) * Z * ST + zb) = qn[k];
                     });
                     own[bc] = L[bc] + run;  // bpsk.py:237
                     hm[bc] = __ballot(!(own[bc] > (T)0));
