@@ -98,6 +98,11 @@ def rooflines(code, cfg, dtype, frames, kernel_ms, executed, kernel, code_name, 
            "rates_gb_s": {"read": LDS_READ64_GBS if itemsize == 8 else LDS_READ32_GBS, "write": LDS_WRITE_GBS}}
     lds["peak"] = (rd + wr) * executed / floor / 1e9      # rate at which this read/write mix could move at best
     lds["frac"] = lds["achieved"] / lds["peak"]
+    qc = getattr(code, "qc", None)
+    if qc is not None and qc.mb <= 4 and kernel.startswith(("spec_r0_", "spec_r1_", "spec_oms_", "fused_spec_")):
+        # the single-wave kernels keep edges of shift 0 inside the lane (registers): that share of the
+        # algorithmic edge traffic above never reaches LDS
+        lds["edge_share_kept_in_registers"] = float((qc.edge_shift == 0).mean())
     out = {"roofline": roof, "lds_roofline": lds}
     sq = _profile_record("sq_counters", key, fixed, kernel)
     if sq:

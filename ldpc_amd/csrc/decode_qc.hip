@@ -218,8 +218,11 @@ __device__ __forceinline__ void var_col(const QcCtx &x, const Cfg<T> &g, const_u
                 q[k + 1] = sw[k] ? a : c;
             }
         }
+        // bpsk.py:244, channel.py:241,358,480: the refresh loop runs over range(self.n), the constructor's
+        // n; a variable beyond it keeps sending its channel value
+        const bool refresh = g.num_refresh_vars < 0 || bc * x.Z + x.z < g.num_refresh_vars;
 #pragma unroll
-        for (int k = 0; k < D; ++k) msg[idx[k]] = q[k];
+        for (int k = 0; k < D; ++k) msg[idx[k]] = refresh ? q[k] : l;
         b = l + run;  // bpsk.py:237
         if (g.clip_post > (T)0) b = clip(b, -g.clip_post, g.clip_post);
         hb[vi] = (uint8_t)hard_bit<RULE>(b);

@@ -75,6 +75,7 @@ struct R0Ctx {
     int Z, FZ, mb, nb;
     int tid, fz0, z;  // tid = f*Z + z, fz0 = f*Z
     int w0, wstep;    // this wave takes block rows / block columns w0, w0 + wstep, ...
+    int mact;         // checks with index >= mact never send a message (ldpc.py:30,175: the loop runs to int(self.m))
 };
 
 // rotated index inside the slot: (z + s) mod Z without a compare (unsigned wrap-around)
@@ -106,7 +107,9 @@ __device__ __forceinline__ int r0_check(const R0Ctx &x, const_u32 info, int e0, 
         if (FLOATCHK) fsum += b;
     }
     if (D < 2) { m1 = (T)0; m2 = (T)0; }  // ldpc.py:178: a check with one variable sends nothing
-    cs[br * x.FZ + x.tid] = Num<T>::make(Num<T>::with_sign(m1, sx), Num<T>::with_sign(m2, sx));
+    unsigned sp = sx;
+    if (br * x.Z + x.z >= x.mact) { m1 = (T)0; m2 = (T)0; sp = 0; }  // beyond int(self.m): its messages stay 0.0
+    cs[br * x.FZ + x.tid] = Num<T>::make(Num<T>::with_sign(m1, sp), Num<T>::with_sign(m2, sp));
     if (FLOATCHK) return !(t_fmod(fsum, (T)2) == (T)0);  // ldpc.py:158,165 on the raw LLRs
     // parity of the hard decisions: hard = 1 - signbit, so the XOR is (D - #negative) mod 2
     return (int)(((unsigned)D ^ (sx >> 31)) & 1u);
@@ -206,6 +209,7 @@ decode_qc_r0_kernel(QcDev q, Cfg<T> g, int F, int W, const TL *__restrict__ llr,
     typedef typename Num<T>::Pair Pair;
     R0Ctx x;
     x.Z = q.Z; x.FZ = F * q.Z; x.mb = q.mb; x.nb = q.nb;
+    x.mact = g.num_active_checks < 0 ? q.mb * q.Z : g.num_active_checks;
     // thread mapping as in decode_qc.hip: a wave covers 64 z of one slot (or 64/Z slots side by side),
     // W wave sets split the block rows / columns of a slot group, G groups share the workgroup
     const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
@@ -337,7 +341,7 @@ static hipError_t launch_r0_t(const QcDev &q, const ldpc_decode_config &cfg, con
     if (grid < 1) grid = 1;
     Cfg<T> g;
     g.rule = 0; g.max_iters = cfg.max_iters; g.early_exit = cfg.early_exit;
-    g.float_syndrome0 = cfg.float_syndrome0; g.num_active_checks = -1; g.num_refresh_vars = -1;
+    g.float_syndrome0 = cfg.float_syndrome0; g.num_active_checks = cfg.num_active_checks; g.num_refresh_vars = -1;
     g.scale = (T)cfg.scale; g.clip_tanh_arg = (T)0; g.clip_prod = (T)0; g.clip_post = (T)0; g.offset = (T)0;
     auto k = decode_qc_r0_kernel<T, TL, DC, DV>;
     hipError_t e = kernel_setup(reinterpret_cast<const void *>(k), sh.threads, lds, nullptr);

@@ -43,16 +43,6 @@ struct SpecLayout {
 // where the check states of a lane fit registers (LOCAL, base graphs of at most four block rows)
 // such an edge's posterior comes from the lane's own register and its check state goes back the
 // same way (`cl`), and only the rotated edges go through LDS.  The values are the same either way.
-template <class C>
-constexpr bool spec_local_edges()
-{
-#ifdef LDPC_NO_LOCAL_EDGES
-    return false;
-#else
-    return C::MB <= 4;
-#endif
-}
-
 template <class C, typename T, bool FLOATCHK>
 __device__ __forceinline__ int spec_r0_checks(const unsigned char *post_b, unsigned char *cs_b, unsigned zb, unsigned zp,
                                               const T (&own)[C::NB], typename SNum<T>::Pair (&cl)[spec_local_edges<C>() ? C::MB : 1])

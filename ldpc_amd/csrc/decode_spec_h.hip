@@ -42,6 +42,7 @@ spec_r1h_kernel(int max_iters, int early_exit, float scale_f, const float *__res
 {
     typedef HalfLayout<C, F> LY;
     constexpr int Z = C::Z, NB = C::NB, MB = C::MB, EB = C::EB, n = NB * Z;
+    constexpr bool LOCAL = spec_local_edges<C>() && LY::QREG;  // edges of shift 0 never leave the lane
     extern __shared__ __align__(16) unsigned char smem[];
 
     const int tid = threadIdx.x;
@@ -68,7 +69,8 @@ spec_r1h_kernel(int max_iters, int early_exit, float scale_f, const float *__res
             own[bc] = l;
             static_for<0, D>([&](auto k) {  // bpsk.py:170-177
                 if constexpr (LY::QREG) q[k0 + k] = l;
-                if (lane_on) *reinterpret_cast<h2 *>(qv_b + (k0 + k) * Z * 4 + zb) = l;  // idle lanes alias lane 0
+                if constexpr (!(LOCAL && C::col_shift[k0 + k] == 0))
+                    if (lane_on) *reinterpret_cast<h2 *>(qv_b + (k0 + k) * Z * 4 + zb) = l;  // idle lanes alias lane 0
             });
         });
 
@@ -84,6 +86,7 @@ spec_r1h_kernel(int max_iters, int early_exit, float scale_f, const float *__res
         };
 
         bool done0 = !act0, done1 = !act1;
+        uint4 cl[LOCAL ? MB : 1];  // check states of this lane's own checks
         for (int t = 0; t < max_iters; ++t) {
             if (early_exit) {  // bpsk.py:205-209, per frame of the pair
                 if (__ballot(!done0) != 0ull) {
@@ -103,7 +106,9 @@ spec_r1h_kernel(int max_iters, int early_exit, float scale_f, const float *__res
                     h2 m1 = kHalfMax2, m2 = kHalfMax2, sx = 0;
                     static_for<0, D>([&](auto p) {
                         constexpr int kpos = C::row_kpos[e0 + p], s = C::row_shift[e0 + p];
-                        const h2 v = *reinterpret_cast<const h2 *>(qv_b + kpos * Z * 4 + rot_fwd<Z, 4, s>(zb));
+                        h2 v;
+                        if constexpr (LOCAL && s == 0) v = q[kpos];
+                        else v = *reinterpret_cast<const h2 *>(qv_b + kpos * Z * 4 + rot_fwd<Z, 4, s>(zb));
                         const h2 a = v & kAbsMask;
                         m2 = pk_min(m2, pk_max(m1, a));
                         m1 = pk_min(m1, a);
@@ -116,6 +121,7 @@ spec_r1h_kernel(int max_iters, int early_exit, float scale_f, const float *__res
                         st = make_uint4(A, B, pk_add(A, B), sx & kSignMask);
                     }
                     *reinterpret_cast<uint4 *>(cs_b + br * Z * 16 + zc) = st;
+                    if constexpr (LOCAL) cl[br] = st;
                 });
                 // ---- variable nodes (bpsk.py:235-247)
                 static_for<0, NB>([&](auto bc) {
@@ -125,7 +131,8 @@ spec_r1h_kernel(int max_iters, int early_exit, float scale_f, const float *__res
                     h2 total = L[bc];
                     static_for<0, D>([&](auto k) {  // all check states of the variable are requested first
                         constexpr int br = C::col_row[k0 + k], s = C::col_shift[k0 + k];
-                        c[k] = *reinterpret_cast<const uint4 *>(cs_b + br * Z * 16 + rot_bwd<Z, 16, s>(zc));
+                        if constexpr (LOCAL && s == 0) c[k] = cl[br];
+                        else c[k] = *reinterpret_cast<const uint4 *>(cs_b + br * Z * 16 + rot_bwd<Z, 16, s>(zc));
                     });
                     static_for<0, D>([&](auto k) {
                         h2 qo;
@@ -138,7 +145,8 @@ spec_r1h_kernel(int max_iters, int early_exit, float scale_f, const float *__res
                     static_for<0, D>([&](auto k) {
                         const h2 qn = pk_sub(total, r[k]);
                         if constexpr (LY::QREG) q[k0 + k] = qn;
-                        *reinterpret_cast<h2 *>(qv_b + (k0 + k) * Z * 4 + zb) = qn;
+                        if constexpr (!(LOCAL && C::col_shift[k0 + k] == 0))
+                            *reinterpret_cast<h2 *>(qv_b + (k0 + k) * Z * 4 + zb) = qn;
                     });
                     own[bc] = total;  // bpsk.py:237
                 });

@@ -345,12 +345,10 @@ static int decode_impl(ldpc_code *c, const ldpc_decode_config *cfg, const void *
         if (!supported) return fail(LDPC_ERR_UNSUPPORTED, "bit flipping keeps 5 n + m bytes of a frame in LDS: the matrix is too large");
         return LDPC_OK;
     }
-    // the loop-bound quirks exist only in the edge-list kernel
+    // the loop-bound quirks exist in the edge-list kernel and in the table-driven circulant kernels
     const bool quirks = (cfg->rule == 0 && cfg->num_active_checks >= 0 && cfg->num_active_checks < c->m) ||
                         (cfg->rule != 0 && cfg->num_refresh_vars >= 0 && cfg->num_refresh_vars < c->n);
     if (kernel == LDPC_KERNEL_QC && !c->has_qc) return fail(LDPC_ERR_ARG, "no QC description attached to this code");
-    if (kernel == LDPC_KERNEL_QC && quirks)
-        return fail(LDPC_ERR_UNSUPPORTED, "num_active_checks / num_refresh_vars need the edge-list kernel");
     if (cfg->rule == LDPC_RULE_LNMS && (quirks || (cfg->num_active_checks >= 0 && cfg->num_active_checks < c->m) || cfg->clip_post > 0.0))
         return fail(LDPC_ERR_UNSUPPORTED, "layered min-sum has no num_active_checks / num_refresh_vars / clip_post");
     // the compiled-in R1 kernels carry no posterior clip (the reference's R1 has none, bpsk.py:235-237)
@@ -372,7 +370,7 @@ static int decode_impl(ldpc_code *c, const ldpc_decode_config *cfg, const void *
         return fail(LDPC_ERR_UNSUPPORTED, "layered min-sum needs a circulant description without double-circulant blocks, "
                                           "check degrees up to 24 and posteriors that fit LDS in the chosen arithmetic");
     }
-    if (kernel != LDPC_KERNEL_CSR && c->has_qc && !quirks) {
+    if (kernel != LDPC_KERNEL_CSR && c->has_qc) {
         bool supported = false;
         hipError_t e = hipSuccess;
         switch (cfg->rule) {

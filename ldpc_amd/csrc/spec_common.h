@@ -156,6 +156,19 @@ template <> struct SNum<double> {
     }
 };
 
+// Edges of shift 0 connect check (br, z) with variable (bc, z), which the same lane owns: where a
+// lane's check states fit registers (base graphs of at most four block rows) the single-wave
+// flooding kernels pass such an edge's message and check state through registers, not LDS.
+template <class C>
+constexpr bool spec_local_edges()
+{
+#ifdef LDPC_NO_LOCAL_EDGES
+    return false;
+#else
+    return C::MB <= 4;
+#endif
+}
+
 constexpr bool is_pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
 
 // byte offset of element ((z + s) mod Z) of a Z-vector with ELEM-byte elements, given zb = z*ELEM

@@ -70,23 +70,38 @@ def test_ccsds_caller_shape():
 
 
 def test_loop_bound_quirks_on_gpu(c_oracle):
-    """self.m / self.n taken from the constructor instead of the matrix (ldpc.py:30,175; bpsk.py:244)."""
+    """self.m / self.n taken from the constructor instead of the matrix (ldpc.py:30,175; bpsk.py:244):
+    served by the table-driven circulant kernels (automatic choice for a circulant code) and by the
+    edge-list kernel, both identical to the CPU restatement.  The cases include the reference's own
+    callers: 8 active rows on the CCSDS matrix (ccsds.py:18) and n = 648 on the 2080-column 5G matrix
+    (channel.py:646)."""
     from ldpc_amd.decoder import Decoder
-    code = codes.load_packaged("wifi648")
-    dec = Decoder(code)
     rng = np.random.default_rng(21)
-    L = 4.0 * (-1.0 + 0.9 * rng.standard_normal((64, code.n)))
-    for cfg in (config.R0.with_(num_active_checks=100), config.R1.with_(num_refresh_vars=300, max_iters=12),
-                config.R2.with_(num_refresh_vars=300, max_iters=8)):
-        eh, ei, ec, ep = c_oracle.c_decode(code, cfg, L if cfg.rule == 0 else -L)
-        res = dec.decode(L if cfg.rule == 0 else -L, cfg, want_posterior=True)
-        assert res.kernel.startswith("csr")          # only the edge-list kernel knows these knobs
-        assert np.array_equal(res.iters, ei) and np.array_equal(res.converged, ec)
-        assert np.array_equal(res.hard, eh)
-        if cfg.rule <= 1:
-            assert np.array_equal(res.posterior, ep)
-        else:
-            np.testing.assert_allclose(res.posterior, ep, rtol=1e-4, atol=1e-7)
+    cases = [("wifi648", config.R0.with_(num_active_checks=100)),
+             ("wifi648", config.R1.with_(num_refresh_vars=300, max_iters=12)),
+             ("wifi648", config.R2.with_(num_refresh_vars=300, max_iters=8)),
+             ("wifi648", config.OMS.with_(num_refresh_vars=40, max_iters=8)),
+             ("ccsds512", config.R0.with_(num_active_checks=8)),
+             ("ccsds512", config.R0.with_(num_active_checks=70)),      # boundary inside a block row
+             ("ccsds512", config.R1.with_(num_refresh_vars=100, max_iters=10)),
+             ("nr_bg2_z40_r1400", config.R3.with_(num_refresh_vars=648, max_iters=10)),
+             ("nr_bg2_z40_r1400", config.R4.with_(num_refresh_vars=648, max_iters=10))]
+    decs = {}
+    for name, cfg in cases:
+        code = codes.load_packaged(name)
+        dec = decs.setdefault(name, Decoder(code))
+        L = 4.0 * (-1.0 + 0.9 * rng.standard_normal((48, code.n)))
+        L = L if cfg.rule == 0 else -L
+        eh, ei, ec, ep = c_oracle.c_decode(code, cfg, L)
+        for kernel, prefix in ((0, "qc"), (1, "csr")):
+            res = dec.decode(L, cfg, want_posterior=True, kernel=kernel)
+            assert res.kernel.startswith(prefix), (name, cfg.rule, res.kernel)
+            assert np.array_equal(res.iters, ei) and np.array_equal(res.converged, ec), (name, cfg.rule, kernel)
+            assert np.array_equal(res.hard, eh), (name, cfg.rule, kernel)
+            if cfg.rule in (0, 1, 6):
+                assert np.array_equal(res.posterior, ep), (name, cfg.rule, kernel)
+            else:
+                np.testing.assert_allclose(res.posterior, ep, rtol=1e-4, atol=1e-7)
 
 
 def test_irregular_matrix_without_circulant_structure(c_oracle):
