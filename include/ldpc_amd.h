@@ -101,6 +101,8 @@ extern "C" {
  *                     the syndrome always uses every row.  -1 = all.
  *   num_refresh_vars  R1-R4: variables [0, k) refresh their variable-to-check messages
  *                     (range(self.n), bpsk.py:244); -1 = all.
+ *                     (Both bounds are served by the table-driven circulant kernels and the
+ *                     edge-list kernel; layered min-sum and the half-precision mode refuse them.)
  *   offset            LDPC_RULE_OMS only: the offset beta (no counterpart in the reference).
  */
 typedef struct ldpc_decode_config {

@@ -36,11 +36,14 @@ namespace ldpc {
 // workgroup writes the LLRs of its current frames to its own slice of `scratch` ([F][n] floats, in
 // device memory but reused frame after frame, hence cache-resident) and decodes from there; llr and
 // the result arrays are unused.
-template <class C, typename T, typename TL, int F, int RL, int WPE, bool FUSED = false>
-__global__ void __launch_bounds__((LnLayout<C, T, F, RL>::THREADS)) __attribute__((amdgpu_waves_per_eu(WPE, 8)))
-lnms_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__restrict__ hard_out,
-            int *__restrict__ iters_out, uint8_t *__restrict__ conv_out, T *__restrict__ post_out, SweepDev sp,
-            float *scratch)
+//
+// WV >= 0: this copy of the code serves wave WV of every slot (lanes z = 64 WV ... 64 WV + 63): for most
+// circulants the wrap of the rotated LDS address is then known at compile time (ln_addr).
+template <class C, typename T, typename TL, int F, int RL, bool FUSED, int WV>
+__device__ __forceinline__ void
+lnms_body(const Cfg<T> &g, const TL *__restrict__ llr, long long frames, uint8_t *__restrict__ hard_out,
+          int *__restrict__ iters_out, uint8_t *__restrict__ conv_out, T *__restrict__ post_out, const SweepDev &sp,
+          float *scratch)
 {
     typedef LnPlan<C> PL;
     typedef LnLayout<C, T, F, RL> LY;
@@ -121,7 +124,7 @@ lnms_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__r
         static_for<0, NB>([&](auto bc) {
             if constexpr (PL::shared(bc)) {
                 const T l = (T)lf[fo + (unsigned)(bc * Z)] + (T)0;  // -0.0 -> +0.0: "negative" is "sign bit set" from here on
-                if (lane_on) lds_put<T>(ln_addr<LY, PL::lds_index(bc), 0>(zb, zbP, zbPW), l);  // idle lanes alias lane 0
+                if (lane_on) lds_put<T>(ln_addr<WV, LY, PL::lds_index(bc), 0>(zb, zbP, zbPW), l);  // idle lanes alias lane 0
             }
         });
         if constexpr (!LY::SINGLE) {
@@ -190,7 +193,7 @@ lnms_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__r
             static_for<0, NB>([&](auto bc) {
                 if constexpr (PL::cdeg(bc) != 1) {
                     T v;
-                    if constexpr (PL::shared(bc)) v = lds_get<T>(ln_addr<LY, PL::lds_index(bc), 0>(zb, zbP, zbPW));
+                    if constexpr (PL::shared(bc)) v = lds_get<T>(ln_addr<WV, LY, PL::lds_index(bc), 0>(zb, zbP, zbPW));
                     else v = (T)lf[fo + (unsigned)(bc * Z)] + (T)0;  // in no check at all: the channel decides
                     hard_out[frame * n + bc * Z + z] = (uint8_t)hard_bit<1>(v);
                     if (post_out) post_out[frame * n + bc * Z + z] = v;
@@ -235,7 +238,7 @@ lnms_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__r
             static_for<0, NB>([&](auto bc) {
                 if constexpr (PL::cdeg(bc) != 1) {
                     T v;
-                    if constexpr (PL::shared(bc)) v = lds_get<T>(ln_addr<LY, PL::lds_index(bc), 0>(zb, zbP, zbPW));
+                    if constexpr (PL::shared(bc)) v = lds_get<T>(ln_addr<WV, LY, PL::lds_index(bc), 0>(zb, zbP, zbPW));
                     else v = (T)lf[fo + (unsigned)(bc * Z)] + (T)0;
                     errs += hard_bit<1>(v) != (rf ? (unsigned)rf[bc * Z + z] : 0u);
                 }
@@ -301,7 +304,7 @@ lnms_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__r
                         static_for<0, D>([&](auto p) {  // all reads of the row first, then their signs
                             if constexpr (p != PP) {
                                 constexpr int bc = C::row_col[e0 + p], s = C::row_shift[e0 + p];
-                                v[p] = lds_get<T>(ln_addr<LY, PL::lds_index(bc), s>(zl, zbP, zbPW));
+                                v[p] = lds_get<T>(ln_addr<WV, LY, PL::lds_index(bc), s>(zl, zbP, zbPW));
                                 if constexpr (ST == 4) __builtin_amdgcn_sched_barrier(0);  // as in the sweep below
                             }
                         });
@@ -372,7 +375,7 @@ lnms_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__r
                                 off[p] = 0;
                             } else {
                                 constexpr int bc = C::row_col[e0 + p], s = C::row_shift[e0 + p];
-                                off[p] = ln_addr<LY, PL::lds_index(bc), s>(zl, zbP, zbPW);
+                                off[p] = ln_addr<WV, LY, PL::lds_index(bc), s>(zl, zbP, zbPW);
                                 q[p] = lds_get<T>(off[p]);
                                 if constexpr (ST == 4) __builtin_amdgcn_sched_barrier(0);  // address, read, address, read: two address blocks in a row cost a wait state
                             }
@@ -432,6 +435,39 @@ lnms_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__r
         if constexpr (!LY::SINGLE) __syncthreads();
     }
     if constexpr (FUSED) acc.flush_wave(sp.counters);
+}
+
+// One copy of the code per wave of a slot where a slot is a whole number of waves (NR BG1 Z = 384: six)
+// and the workgroup has several; every wave executes the same barriers in the same order in its own copy.
+// A switch for kernel experiments, off by default: measured on BG1 in float it removes 9.4 % of the
+// vector instructions (28 600 instead of 31 600 per frame-sweep) and not a microsecond of the run
+// time (the waiting share of the wave cycles grows from 37 % to 42 %): the twelve waves of a workgroup
+// move from barrier to barrier together, and what a layer costs is its chain of dependent instructions
+// and LDS round trips, not the number of instructions issued beside it.
+#ifndef LDPC_LNMS_WAVE_COPIES
+#define LDPC_LNMS_WAVE_COPIES 0
+#endif
+template <class C, typename T, int F, bool FUSED>
+constexpr int lnms_wave_copies()
+{
+    return (LDPC_LNMS_WAVE_COPIES && !FUSED && sizeof(T) == 4 && C::Z % 64 == 0 && C::Z / 64 >= 2 && C::Z / 64 <= 8) ? C::Z / 64 : 0;
+}
+
+template <class C, typename T, typename TL, int F, int RL, int WPE, bool FUSED = false>
+__global__ void __launch_bounds__((LnLayout<C, T, F, RL>::THREADS)) __attribute__((amdgpu_waves_per_eu(WPE, 8)))
+lnms_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__restrict__ hard_out,
+            int *__restrict__ iters_out, uint8_t *__restrict__ conv_out, T *__restrict__ post_out, SweepDev sp,
+            float *scratch)
+{
+    constexpr int NW = lnms_wave_copies<C, T, F, FUSED>();
+    if constexpr (NW == 0) {
+        lnms_body<C, T, TL, F, RL, FUSED, -1>(g, llr, frames, hard_out, iters_out, conv_out, post_out, sp, scratch);
+    } else {
+        const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) % NW;  // wave-uniform: a scalar branch
+        static_for<0, NW>([&](auto w) {
+            if (wv == w) lnms_body<C, T, TL, F, RL, FUSED, w>(g, llr, frames, hard_out, iters_out, conv_out, post_out, sp, scratch);
+        });
+    }
 }
 
 // ------------------------------------------------------------------------------------------ host

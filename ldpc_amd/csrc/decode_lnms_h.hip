@@ -139,7 +139,7 @@ lnms_h_kernel(int max_iters, int early_exit, float scale_f, const float *__restr
         static_for<0, NB>([&](auto bc) {
             if constexpr (PL::shared(bc)) {
                 const h2 l = load_pair(bc * Z);
-                if (lane_on) lds_put<h2>(ln_addr<LY, PL::lds_index(bc), 0>(zb, zbP, zbPW), l);  // idle lanes alias lane 0
+                if (lane_on) lds_put<h2>(ln_addr<-1, LY, PL::lds_index(bc), 0>(zb, zbP, zbPW), l);  // idle lanes alias lane 0
                 if constexpr (PL::lds_index(bc) % 8 == 7) __builtin_amdgcn_sched_barrier(0);  // eight columns in flight at a time
             }
         });
@@ -218,7 +218,7 @@ lnms_h_kernel(int max_iters, int early_exit, float scale_f, const float *__restr
             static_for<0, NB>([&](auto bc) {
                 if constexpr (PL::cdeg(bc) != 1) {
                     h2 v;
-                    if constexpr (PL::shared(bc)) v = lds_get<h2>(ln_addr<LY, PL::lds_index(bc), 0>(zb, zbP, zbPW));
+                    if constexpr (PL::shared(bc)) v = lds_get<h2>(ln_addr<-1, LY, PL::lds_index(bc), 0>(zb, zbP, zbPW));
                     else v = load_pair(bc * Z);  // in no check at all: the channel decides
                     hg[ho + (unsigned)(bc * Z)] = (uint8_t)((v >> sh) & 1u);
                     if constexpr (bc % 4 == 3) __builtin_amdgcn_sched_barrier(0);  // a few columns in flight, not all: registers
@@ -278,7 +278,7 @@ lnms_h_kernel(int max_iters, int early_exit, float scale_f, const float *__restr
                         static_for<0, D>([&](auto p) {  // all reads of the row first, then their signs
                             if constexpr (p != PP) {
                                 constexpr int bc = C::row_col[e0 + p], s = C::row_shift[e0 + p];
-                                v[p] = lds_get<h2>(ln_addr<LY, PL::lds_index(bc), s>(zl, zbP, zbPW));
+                                v[p] = lds_get<h2>(ln_addr<-1, LY, PL::lds_index(bc), s>(zl, zbP, zbPW));
                                 __builtin_amdgcn_sched_barrier(0);
                             }
                         });
@@ -345,7 +345,7 @@ lnms_h_kernel(int max_iters, int early_exit, float scale_f, const float *__restr
                         static_for<0, D>([&](auto p) {
                             if constexpr (p != PP) {
                                 constexpr int bc = C::row_col[e0 + p], s = C::row_shift[e0 + p];
-                                const unsigned ad = ln_addr<LY, PL::lds_index(bc), s>(zl, zbP, zbPW);
+                                const unsigned ad = ln_addr<-1, LY, PL::lds_index(bc), s>(zl, zbP, zbPW);
                                 off[LONG ? 0 : (int)p] = ad;
                                 q[p] = lds_get<h2>(ad);
                                 __builtin_amdgcn_sched_barrier(0);  // address, read, address, read
@@ -390,7 +390,7 @@ lnms_h_kernel(int max_iters, int early_exit, float scale_f, const float *__restr
                             if constexpr (p != PP) {
                                 if constexpr (LONG) {  // a long row's addresses are formed again: keeping them costs registers
                                     constexpr int bc = C::row_col[e0 + p], s = C::row_shift[e0 + p];
-                                    lds_put<h2>(ln_addr<LY, PL::lds_index(bc), s>(zl, zbP, zbPW), pn);
+                                    lds_put<h2>(ln_addr<-1, LY, PL::lds_index(bc), s>(zl, zbP, zbPW), pn);
                                 } else {
                                     lds_put<h2>(off[p], pn);
                                 }

@@ -149,10 +149,18 @@ struct LnLayout {
 // zbPW = zbP + one vector.  The wrapped and the unwrapped case differ by one vector, so one
 // compare against a constant and one select pick the base register, and everything else is a
 // constant that lands in the instruction's offset field.
-template <class LY, int CI, int S>
+// WV >= 0: the code is compiled for wave WV of a slot, i.e. for z in [64 WV, 64 WV + 63].  All of a
+// wave's lanes wrap, or none does, except in the one wave that holds the boundary Z - S: the others
+// need no instruction at all for the address.
+template <int WV, class LY, int CI, int S>
 __device__ __forceinline__ unsigned ln_addr(unsigned zl, unsigned zbP, unsigned zbPW)
 {
+    constexpr int Zc = LY::VEC / LY::ST;
     if constexpr (S == 0) return zbP + (unsigned)(LY::P_OFF + CI * LY::VEC);
+    else if constexpr (WV >= 0 && 64 * WV >= Zc - S)
+        return zbP + (unsigned)(LY::P_OFF + CI * LY::VEC + S * LY::ST - LY::VEC);  // every lane wraps
+    else if constexpr (WV >= 0 && 64 * WV + 63 < Zc - S)
+        return zbP + (unsigned)(LY::P_OFF + CI * LY::VEC + S * LY::ST);            // no lane wraps
     else {
         unsigned base;  // = zl >= VEC - S ST ? zbP : zbPW
         if constexpr (LY::ST == 4) {
