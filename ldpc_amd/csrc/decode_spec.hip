@@ -300,11 +300,22 @@ spec_r0_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *
 template <class C, typename T, int F>
 struct R1Layout {
     static constexpr int THREADS = ((F * C::Z + 63) / 64) * 64;
-    static constexpr int QV_BYTES = C::EB * C::Z * (int)sizeof(T);
+    static constexpr bool QREG = C::EB * (int)sizeof(T) / 4 <= 72;  // own messages in registers
+    // edges of shift 0 stay inside the lane (see spec_r0_checks): their messages live in registers only
+    // and have no place in LDS; row(e) = place of the message of edge e (variable order) in qv
+    static constexpr bool LOCAL = spec_local_edges<C>() && QREG;
+    static constexpr bool local(int e) { return LOCAL && C::col_shift[e] == 0; }
+    static constexpr int row(int e)
+    {
+        int k = 0;
+        for (int i = 0; i < e; ++i) k += !local(i);
+        return k;
+    }
+    static constexpr int QV_BYTES = row(C::EB) * C::Z * (int)sizeof(T);
+    static_assert(QV_BYTES % (2 * (int)sizeof(T)) == 0, "the check states behind the messages are aligned pairs");
     static constexpr int CS_BYTES = C::MB * C::Z * 2 * (int)sizeof(T);
     static constexpr int SLOT_BYTES = ((QV_BYTES + CS_BYTES + 127) / 128) * 128 + (F > 1 ? 32 : 0);
     static constexpr int LDS_BYTES = F * SLOT_BYTES;
-    static constexpr bool QREG = C::EB * (int)sizeof(T) / 4 <= 72;  // own messages in registers
 };
 
 template <class C, typename T, typename TL, int F, bool OMS, bool FUSED = false>  // OMS: the offset rule (LDPC_RULE_OMS) instead of R1's; FUSED: as in spec_r0_kernel
@@ -317,9 +328,14 @@ spec_r1_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *
     static_assert(LY::THREADS == 64, "single-wave workgroups only");
     constexpr int Z = C::Z, NB = C::NB, MB = C::MB, EB = C::EB, ST = sizeof(T), SP = 2 * sizeof(T);
     constexpr int n = NB * Z;
-    // edges of shift 0 stay inside the lane (see spec_r0_checks): their message and their check state
-    // are never written to LDS
-    constexpr bool LOCAL = spec_local_edges<C>() && LY::QREG;
+    constexpr bool LOCAL = LY::LOCAL;  // edges of shift 0: message and check state never written to LDS
+    // with local edges only THEIR messages have to live in registers; the others can be read back
+    // from the lane's own LDS slot, which frees registers for one more wave per SIMD
+#ifndef LDPC_R1_QLOCAL
+#define LDPC_R1_QLOCAL 0
+#endif
+    constexpr bool QLOCAL = LOCAL && LDPC_R1_QLOCAL;
+    auto q_in_reg = [](auto e) constexpr { return LY::QREG && (!QLOCAL || C::col_shift[e] == 0); };
     extern __shared__ __align__(16) unsigned char smem[];
 
     const int tid = threadIdx.x;
@@ -363,9 +379,9 @@ spec_r1_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *
             own[bc] = l;
             hm[bc] = __ballot(!(l > (T)0));
             static_for<0, D>([&](auto k) {  // bpsk.py:170-177
-                if constexpr (LY::QREG) q[k0 + k] = l;
+                if constexpr (q_in_reg(IC<k0 + k>{})) q[k0 + k] = l;
                 if constexpr (!(LOCAL && C::col_shift[k0 + k] == 0)) {
-                    if (lane_on) *reinterpret_cast<T *>(qv_b + (k0 + k) * Z * ST + zb) = l;  // idle lanes alias lane 0
+                    if (lane_on) *reinterpret_cast<T *>(qv_b + LY::row(k0 + k) * Z * ST + zb) = l;  // idle lanes alias lane 0
                 }
             });
         });
@@ -406,7 +422,7 @@ spec_r1_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *
                         constexpr int kpos = C::row_kpos[e0 + p], s = C::row_shift[e0 + p];
                         T v;
                         if constexpr (LOCAL && s == 0) v = q[kpos];
-                        else v = *reinterpret_cast<const T *>(qv_b + kpos * Z * ST + rot_fwd<Z, ST, s>(zb));
+                        else v = *reinterpret_cast<const T *>(qv_b + LY::row(kpos) * Z * ST + rot_fwd<Z, ST, s>(zb));
                         SNum<T>::template book<p>(m1, m2, v);
                         sx ^= SNum<T>::sign_word(v);
                     });
@@ -423,8 +439,8 @@ spec_r1_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *
                     static_for<0, D>([&](auto k) {
                         constexpr int br = C::col_row[k0 + k], s = C::col_shift[k0 + k];
                         T qo;
-                        if constexpr (LY::QREG) qo = q[k0 + k];
-                        else qo = *reinterpret_cast<const T *>(qv_b + (k0 + k) * Z * ST + zb);
+                        if constexpr (q_in_reg(IC<k0 + k>{})) qo = q[k0 + k];
+                        else qo = *reinterpret_cast<const T *>(qv_b + LY::row(k0 + k) * Z * ST + zb);
                         off[k] = rot_bwd<Z, SP, s>(zp);
                         Pair c;
                         if constexpr (LOCAL && s == 0) c = cl[br];
@@ -460,9 +476,9 @@ spec_r1_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *
                         }
                     });
                     static_for<0, D>([&](auto k) {
-                        if constexpr (LY::QREG) q[k0 + k] = qn[k];
+                        if constexpr (q_in_reg(IC<k0 + k>{})) q[k0 + k] = qn[k];
                         if constexpr (!(LOCAL && C::col_shift[k0 + k] == 0))
-                            *reinterpret_cast<T *>(qv_b + (k0 + k) * Z * ST + zb) = qn[k];
+                            *reinterpret_cast<T *>(qv_b + LY::row(k0 + k) * Z * ST + zb) = qn[k];
                     });
                     own[bc] = L[bc] + run;  // bpsk.py:237
                     hm[bc] = __ballot(!(own[bc] > (T)0));
