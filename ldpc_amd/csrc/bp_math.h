@@ -38,6 +38,13 @@ __device__ inline float t_log(float x) { return logf(x); }
 __device__ inline double t_log(double x) { return log(x); }
 __device__ inline float t_fmod(float x, float y) { return fmodf(x, y); }
 __device__ inline double t_fmod(double x, double y) { return fmod(x, y); }
+// `x % 2 == 0` of the reference's iteration-0 syndrome on raw LLR sums (ldpc.py:79 on floats): true
+// exactly when x is finite and an even integer (+-0 included), which is what fmod(x, 2) == 0 says.
+// Halving is exact, so x is an even integer iff twice the truncated half gives x back (a tiny x
+// whose half rounds to zero fails the comparison, as it should); three instructions where the
+// library's fmod is a loop.
+__device__ inline bool even_integer(float x) { const float t = truncf(x * 0.5f); return t + t == x && fabsf(x) < __builtin_inff(); }
+__device__ inline bool even_integer(double x) { const double t = trunc(x * 0.5); return t + t == x && fabs(x) < __builtin_inf(); }
 
 template <typename T>
 __device__ inline T clip(T x, T lo, T hi) { return x < lo ? lo : (x > hi ? hi : x); }

@@ -84,7 +84,7 @@ __global__ void decode_csr_kernel(CsrDev c, Cfg<T> g, const TL *__restrict__ llr
                         // numpy.dot(H, llr) % 2 == 0 on the float LLRs (ldpc.py:158,165)
                         T s = (T)0;
                         for (int e = e0; e < e1; ++e) s += post[c.col_idx[e]];
-                        bad |= !(t_fmod(s, (T)2) == (T)0);
+                        bad |= !even_integer(s);
                     } else {
                         unsigned p = 0;
                         for (int e = e0; e < e1; ++e) p ^= hb[c.col_idx[e]];

@@ -97,7 +97,7 @@ __device__ __forceinline__ int check_row(const QcCtx &x, const Cfg<T> &g, const_
             T s = (T)0;
 #pragma unroll
             for (int p = 0; p < D; ++p) s += v[p];
-            bad = !(t_fmod(s, (T)2) == (T)0);
+            bad = !even_integer(s);
         } else {
 #pragma unroll
             for (int p = 0; p < D; ++p) par ^= hard_bit<0>(v[p]);

@@ -110,7 +110,7 @@ __device__ __forceinline__ int r0_check(const R0Ctx &x, const_u32 info, int e0, 
     unsigned sp = sx;
     if (br * x.Z + x.z >= x.mact) { m1 = (T)0; m2 = (T)0; sp = 0; }  // beyond int(self.m): its messages stay 0.0
     cs[br * x.FZ + x.tid] = Num<T>::make(Num<T>::with_sign(m1, sp), Num<T>::with_sign(m2, sp));
-    if (FLOATCHK) return !(t_fmod(fsum, (T)2) == (T)0);  // ldpc.py:158,165 on the raw LLRs
+    if (FLOATCHK) return !even_integer(fsum);  // ldpc.py:158,165 on the raw LLRs
     // parity of the hard decisions: hard = 1 - signbit, so the XOR is (D - #negative) mod 2
     return (int)(((unsigned)D ^ (sx >> 31)) & 1u);
 }

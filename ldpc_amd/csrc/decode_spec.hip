@@ -69,7 +69,7 @@ __device__ __forceinline__ int spec_r0_checks(const unsigned char *post_b, unsig
         const Pair cst = SNum<T>::make(SNum<T>::with_sign(m1, sx), SNum<T>::with_sign(m2, sx));
         *reinterpret_cast<Pair *>(cs_b + br * Z * SP + zp) = cst;
         if constexpr (LOCAL) cl[br] = cst;
-        if constexpr (FLOATCHK) bad |= !(t_fmod(fsum, (T)2) == (T)0);
+        if constexpr (FLOATCHK) bad |= !even_integer(fsum);
         else bad |= (int)(((unsigned)D ^ (sx >> 31)) & 1u);  // parity of the hard bits 1 - signbit
     });
     return bad;
@@ -347,7 +347,8 @@ spec_r1_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *
     const unsigned zb = (unsigned)z * ST, zp = (unsigned)z * SP;
     const unsigned long long slot_mask = (Z >= 64 ? ~0ull : ((1ull << (Z & 63)) - 1ull)) << ((f * Z) & 63);
 
-    constexpr bool PREFETCH = !FUSED && llr_prefetch_pays<C, TL>(LY::LDS_BYTES);  // see llr_prefetch
+    // in double with the messages in registers two waves per SIMD (eight workgroups) are all the registers allow
+    constexpr bool PREFETCH = !FUSED && llr_prefetch_pays<C, TL>(LY::LDS_BYTES, sizeof(T) == 8 && LY::QREG ? 8 : 12);  // see llr_prefetch
     __shared__ float stage[PREFETCH ? NB * 64 : 1];  // [NB][lane]
     __shared__ __align__(16) float fstage[FUSED ? F * n : 1];  // fused: channel LLRs by position
     __shared__ __align__(4) uint8_t fref[FUSED ? F * n : 4];   //        and the transmitted bits

@@ -500,7 +500,7 @@ spec_r0w_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t 
                                 if (!last)
                                     *reinterpret_cast<Pair *>(cs_b + br * Z * SP + zp) =
                                         SNum<T>::make(SNum<T>::with_sign(m1, sx), SNum<T>::with_sign(m2, sx));
-                                if constexpr (FC) bad |= !(t_fmod(fsum, (T)2) == (T)0);
+                                if constexpr (FC) bad |= !even_integer(fsum);
                                 else bad |= ((unsigned)D ^ (sx >> 31)) & 1u;  // parity of the hard bits 1 - signbit
                             }
                         });

@@ -195,10 +195,11 @@ __device__ __forceinline__ unsigned rot_bwd(unsigned zb)
 // refilling it.  Lanes without a frame read frame 0, which exists.
 // Worth it only while LDS is not what limits residency: with the staging area at least twelve
 // single-wave workgroups (three per SIMD) must still fit a compute unit.
+// (a kernel whose registers allow fewer workgroups anyway passes that number as `wanted`)
 template <class C, typename TL>
-constexpr bool llr_prefetch_pays(int lds_bytes)
+constexpr bool llr_prefetch_pays(int lds_bytes, int wanted = 12)
 {
-    return sizeof(TL) == 4 && (160 * 1024) / (lds_bytes + C::NB * 256) >= 12;
+    return sizeof(TL) == 4 && (160 * 1024) / (lds_bytes + C::NB * 256) >= wanted;
 }
 template <class C, int F>
 __device__ __forceinline__ void llr_prefetch(float *stage, const float *llr, long long group, long long frames,
