@@ -27,12 +27,25 @@ namespace ldpc {
 template <class C, int F>
 struct HalfLayout {
     static constexpr int THREADS = ((F * C::Z + 63) / 64) * 64;
-    static constexpr int QV_BYTES = C::EB * C::Z * 4;
+    static constexpr bool QREG = C::EB <= 72;  // own messages in registers
+    // edges of shift 0 never leave the lane: their messages live in registers only and have no place
+    // in LDS; row(e) = place of the message of edge e (variable order) in qv
+    static constexpr bool LOCAL = spec_local_edges<C>() && QREG;
+    static constexpr bool local(int e) { return LOCAL && C::col_shift[e] == 0; }
+    static constexpr int row(int e)
+    {
+        int k = 0;
+        for (int i = 0; i < e; ++i) k += !local(i);
+        return k;
+    }
+    static constexpr int QV_BYTES = ((row(C::EB) * C::Z * 4 + 15) / 16) * 16;
     static constexpr int CS_BYTES = C::MB * C::Z * 16;  // A, B, A + B, sign parities
     static constexpr int SLOT_BYTES = ((QV_BYTES + CS_BYTES + 127) / 128) * 128 + (F > 1 ? 32 : 0);
     static constexpr int LDS_BYTES = F * SLOT_BYTES;
-    static constexpr bool QREG = C::EB <= 72;  // own messages in registers
     static constexpr bool OK = THREADS == 64 && C::EB <= 100 && LDS_BYTES <= 64 * 1024;
+    // the next pair's LLRs are fetched into an LDS staging area during the decode (llr_prefetch_frame)
+    // where that still leaves twelve workgroups per compute unit
+    static constexpr bool PREFETCH = F == 1 && (160 * 1024) / (LDS_BYTES + 2 * C::NB * 256) >= 12;
 };
 
 template <class C, int F>
@@ -42,7 +55,7 @@ spec_r1h_kernel(int max_iters, int early_exit, float scale_f, const float *__res
 {
     typedef HalfLayout<C, F> LY;
     constexpr int Z = C::Z, NB = C::NB, MB = C::MB, EB = C::EB, n = NB * Z;
-    constexpr bool LOCAL = spec_local_edges<C>() && LY::QREG;  // edges of shift 0 never leave the lane
+    constexpr bool LOCAL = LY::LOCAL;  // edges of shift 0 never leave the lane
     extern __shared__ __align__(16) unsigned char smem[];
 
     const int tid = threadIdx.x;
@@ -56,21 +69,46 @@ spec_r1h_kernel(int max_iters, int early_exit, float scale_f, const float *__res
     const h2 scale2 = pack_half2(scale_f, scale_f);
 
     const long long pairs = (frames + 1) / 2, groups = (pairs + F - 1) / F;
+    constexpr bool PREFETCH = LY::PREFETCH;
+    __shared__ float stage[PREFETCH ? 2 * NB * 64 : 1];  // [frame of the pair][NB][lane]
+    auto prefetch = [&](long long g2) {
+        if constexpr (PREFETCH) {
+            const long long a = (g2 * F + f) * 2;
+            llr_prefetch_frame<C>(stage, llr, a, lane_on && a < frames, z);
+            llr_prefetch_frame<C>(stage + NB * 64, llr, a + 1, lane_on && a + 1 < frames, z);
+        }
+    };
+    if (blockIdx.x < groups) prefetch(blockIdx.x);
     for (long long grp = blockIdx.x; grp < groups; grp += gridDim.x) {
         const long long fr0 = (grp * F + f) * 2, fr1 = fr0 + 1;
         const bool act0 = lane_on && fr0 < frames, act1 = lane_on && fr1 < frames;
         h2 L[NB], own[NB];
         h2 q[LY::QREG ? EB : 1];
+        if constexpr (PREFETCH) __builtin_amdgcn_s_waitcnt(0);  // the staged LLRs have landed
+        float l0s[NB], l1s[NB];
+        static_for<0, NB>([&](auto bc) {
+            if constexpr (PREFETCH) {
+                l0s[bc] = act0 ? stage[bc * 64 + tid] : 0.0f;
+                l1s[bc] = act1 ? stage[NB * 64 + bc * 64 + tid] : 0.0f;
+            } else {
+                l0s[bc] = act0 ? llr[fr0 * n + bc * Z + z] : 0.0f;
+                l1s[bc] = act1 ? llr[fr1 * n + bc * Z + z] : 0.0f;
+            }
+        });
+        if constexpr (PREFETCH) {
+            __builtin_amdgcn_s_waitcnt(0);  // staging area read out before it is refilled
+            if (grp + gridDim.x < groups) prefetch(grp + gridDim.x);
+        }
         static_for<0, NB>([&](auto bc) {
             constexpr int k0 = C::col_ptr[bc], D = C::col_ptr[bc + 1] - k0;
-            const float l0 = act0 ? llr[fr0 * n + bc * Z + z] : 0.0f, l1 = act1 ? llr[fr1 * n + bc * Z + z] : 0.0f;
+            const float l0 = l0s[bc], l1 = l1s[bc];
             const h2 l = pack_half2(l0, l1);
             L[bc] = l;
             own[bc] = l;
             static_for<0, D>([&](auto k) {  // bpsk.py:170-177
                 if constexpr (LY::QREG) q[k0 + k] = l;
                 if constexpr (!(LOCAL && C::col_shift[k0 + k] == 0))
-                    if (lane_on) *reinterpret_cast<h2 *>(qv_b + (k0 + k) * Z * 4 + zb) = l;  // idle lanes alias lane 0
+                    if (lane_on) *reinterpret_cast<h2 *>(qv_b + LY::row(k0 + k) * Z * 4 + zb) = l;  // idle lanes alias lane 0
             });
         });
 
@@ -108,7 +146,7 @@ spec_r1h_kernel(int max_iters, int early_exit, float scale_f, const float *__res
                         constexpr int kpos = C::row_kpos[e0 + p], s = C::row_shift[e0 + p];
                         h2 v;
                         if constexpr (LOCAL && s == 0) v = q[kpos];
-                        else v = *reinterpret_cast<const h2 *>(qv_b + kpos * Z * 4 + rot_fwd<Z, 4, s>(zb));
+                        else v = *reinterpret_cast<const h2 *>(qv_b + LY::row(kpos) * Z * 4 + rot_fwd<Z, 4, s>(zb));
                         const h2 a = v & kAbsMask;
                         m2 = pk_min(m2, pk_max(m1, a));
                         m1 = pk_min(m1, a);
@@ -137,7 +175,7 @@ spec_r1h_kernel(int max_iters, int early_exit, float scale_f, const float *__res
                     static_for<0, D>([&](auto k) {
                         h2 qo;
                         if constexpr (LY::QREG) qo = q[k0 + k];
-                        else qo = *reinterpret_cast<const h2 *>(qv_b + (k0 + k) * Z * 4 + zb);
+                        else qo = *reinterpret_cast<const h2 *>(qv_b + LY::row(k0 + k) * Z * 4 + zb);
                         const h2 mag = pk_min(c[k].y, pk_max(c[k].x, pk_fnma(qo & kAbsMask, scale2, c[k].z)));
                         r[k] = mag ^ ((qo ^ c[k].w) & kSignMask);  // sign = parity of the check without this input
                         total = pk_add(total, r[k]);
@@ -146,7 +184,7 @@ spec_r1h_kernel(int max_iters, int early_exit, float scale_f, const float *__res
                         const h2 qn = pk_sub(total, r[k]);
                         if constexpr (LY::QREG) q[k0 + k] = qn;
                         if constexpr (!(LOCAL && C::col_shift[k0 + k] == 0))
-                            *reinterpret_cast<h2 *>(qv_b + (k0 + k) * Z * 4 + zb) = qn;
+                            *reinterpret_cast<h2 *>(qv_b + LY::row(k0 + k) * Z * 4 + zb) = qn;
                     });
                     own[bc] = total;  // bpsk.py:237
                 });

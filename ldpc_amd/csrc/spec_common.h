@@ -217,6 +217,19 @@ __device__ __forceinline__ void llr_prefetch(float *stage, const float *llr, lon
 }
 template <class C, int F>
 __device__ __forceinline__ void llr_prefetch(float *, const double *, long long, long long, bool, int, int) {}
+// the same for one frame given by its index (lanes without a frame pass `valid` = false and read frame 0)
+template <class C>
+__device__ __forceinline__ void llr_prefetch_frame(float *stage, const float *llr, long long frame, bool valid, int z)
+{
+    const float *src = llr + (valid ? frame : 0) * (C::NB * C::Z) + z;
+    const unsigned base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) float *)stage;
+    static_for<0, C::NB>([&](auto bc) {
+        const float *from = src + bc * C::Z;
+        const unsigned to = base + bc * 256u;
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off"
+                     :: "v"(from), "s"(to) : "memory");
+    });
+}
 
 // Hard decisions as ballots: one 64-bit lane mask per block column; the syndrome of a block row is
 // the XOR of those masks rotated by the circulant shifts (scalar instructions only).
