@@ -402,7 +402,8 @@ def link_workloads(head, bg2, args, torch, dist, device, world, rank):
     res = {}
     code, dec = head.code, head.dec
     frames = min(args.frames, 1 << 19)
-    for label, rule, dtype, snr in (("sweep_R0_f64_es_n0_1dB", "R0", np.float64, 1.0), ("sweep_R1_f32_es_n0_1dB", "R1", np.float32, 1.0)):
+    for label, rule, dtype, snr in (("sweep_R0_f64_es_n0_1dB", "R0", np.float64, 1.0), ("sweep_R1_f32_es_n0_1dB", "R1", np.float32, 1.0),
+                                    ("sweep_R1_f16x2_es_n0_1dB", "R1", np.float16, 1.0)):   # packed half precision: reduced precision
         cfg = config.PRESETS[rule].with_(max_iters=args.max_iters)
         cw = sweep.make_codewords(code, head.G, frames, [31, rank], device)
         ctr = torch.zeros((5,), dtype=torch.int64, device=device)

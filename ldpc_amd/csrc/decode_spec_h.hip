@@ -21,6 +21,7 @@
 // that no sum of up to 30 messages leaves the half-precision range.
 #include "spec_common.h"
 #include "half2_ops.h"
+#include "sweep_fused.h"
 
 namespace ldpc {
 
@@ -48,10 +49,13 @@ struct HalfLayout {
     static constexpr bool PREFETCH = F == 1 && (160 * 1024) / (LDS_BYTES + 2 * C::NB * 256) >= 12;
 };
 
-template <class C, int F>
+// FUSED: the channel in front and the error accounting behind run inside the kernel (sweep_fused.h):
+// the LLRs of a slot's two frames are drawn into an LDS staging area, results go into the counters;
+// llr and the result arrays are unused.
+template <class C, int F, bool FUSED = false>
 __global__ void __launch_bounds__(64)
 spec_r1h_kernel(int max_iters, int early_exit, float scale_f, const float *__restrict__ llr, long long frames,
-                uint8_t *__restrict__ hard_out, int *__restrict__ iters_out, uint8_t *__restrict__ conv_out)
+                uint8_t *__restrict__ hard_out, int *__restrict__ iters_out, uint8_t *__restrict__ conv_out, SweepDev sp)
 {
     typedef HalfLayout<C, F> LY;
     constexpr int Z = C::Z, NB = C::NB, MB = C::MB, EB = C::EB, n = NB * Z;
@@ -69,8 +73,11 @@ spec_r1h_kernel(int max_iters, int early_exit, float scale_f, const float *__res
     const h2 scale2 = pack_half2(scale_f, scale_f);
 
     const long long pairs = (frames + 1) / 2, groups = (pairs + F - 1) / F;
-    constexpr bool PREFETCH = LY::PREFETCH;
+    constexpr bool PREFETCH = LY::PREFETCH && !FUSED;
     __shared__ float stage[PREFETCH ? 2 * NB * 64 : 1];  // [frame of the pair][NB][lane]
+    __shared__ __align__(16) float fstage[FUSED ? 2 * F * n : 1];  // fused: channel LLRs by position, frame 2 f + h of the group
+    __shared__ __align__(4) uint8_t fref[FUSED ? 2 * F * n : 4];   //        and the transmitted bits
+    SweepAcc acc;
     auto prefetch = [&](long long g2) {
         if constexpr (PREFETCH) {
             const long long a = (g2 * F + f) * 2;
@@ -85,9 +92,16 @@ spec_r1h_kernel(int max_iters, int early_exit, float scale_f, const float *__res
         h2 L[NB], own[NB];
         h2 q[LY::QREG ? EB : 1];
         if constexpr (PREFETCH) __builtin_amdgcn_s_waitcnt(0);  // the staged LLRs have landed
+        if constexpr (FUSED) {  // one wave: its LDS operations execute in order, no barrier needed
+            sweep_stage_wave<n, 2 * F>(sp, fstage, fref, grp, frames, tid);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
         float l0s[NB], l1s[NB];
         static_for<0, NB>([&](auto bc) {
-            if constexpr (PREFETCH) {
+            if constexpr (FUSED) {
+                l0s[bc] = act0 ? fstage[(2 * f) * n + bc * Z + z] : 0.0f;
+                l1s[bc] = act1 ? fstage[(2 * f + 1) * n + bc * Z + z] : 0.0f;
+            } else if constexpr (PREFETCH) {
                 l0s[bc] = act0 ? stage[bc * 64 + tid] : 0.0f;
                 l1s[bc] = act1 ? stage[NB * 64 + bc * 64 + tid] : 0.0f;
             } else {
@@ -119,8 +133,16 @@ spec_r1h_kernel(int max_iters, int early_exit, float scale_f, const float *__res
             return r1_slot_ok<C, F>(hm, slot_mask);
         };
         auto write_half = [&](auto h, long long frame, int iters, int conv) {
-            static_for<0, NB>([&](auto bc) { hard_out[frame * n + bc * Z + z] = half_positive(own[bc], h) ? 0 : 1; });
-            if (z == 0) { iters_out[frame] = iters; conv_out[frame] = (uint8_t)conv; }
+            if constexpr (FUSED) {
+                unsigned errs = 0;
+                static_for<0, NB>([&](auto bc) {
+                    errs += (unsigned)(half_positive(own[bc], h) ? 0 : 1) != (unsigned)fref[(2 * f + h) * n + bc * Z + z];
+                });
+                acc.book(errs, (__ballot(errs != 0) & slot_mask) != 0ull, z == 0, iters, conv);
+            } else {
+                static_for<0, NB>([&](auto bc) { hard_out[frame * n + bc * Z + z] = half_positive(own[bc], h) ? 0 : 1; });
+                if (z == 0) { iters_out[frame] = iters; conv_out[frame] = (uint8_t)conv; }
+            }
         };
 
         bool done0 = !act0, done1 = !act1;
@@ -199,13 +221,15 @@ spec_r1h_kernel(int max_iters, int early_exit, float scale_f, const float *__res
             else write_half(IC<1>{}, fr1, max_iters, frame_ok(IC<1>{}) ? 1 : 0);
         }
     }
+    if constexpr (FUSED) acc.flush_wave(sp.counters);
 }
 
-template <class C, int F>
-static hipError_t launch_r1h(const ldpc_decode_config &cfg, const Launch &io, int num_cus, const char **name)
+template <class C, int F, bool FUSED = false>
+static hipError_t launch_r1h(const ldpc_decode_config &cfg, const Launch &io, int num_cus, const char **name,
+                             const SweepDev *sp = nullptr)
 {
     typedef HalfLayout<C, F> LY;
-    auto k = spec_r1h_kernel<C, F>;
+    auto k = spec_r1h_kernel<C, F, FUSED>;
     int per_cu = 0;
     hipError_t e = kernel_setup(reinterpret_cast<const void *>(k), 64, LY::LDS_BYTES, &per_cu);
     if (e != hipSuccess) return e;
@@ -215,8 +239,9 @@ static hipError_t launch_r1h(const ldpc_decode_config &cfg, const Launch &io, in
     if (grid > groups) grid = groups;
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(64), LY::LDS_BYTES, io.stream, cfg.max_iters, cfg.early_exit,
-                       (float)cfg.scale, reinterpret_cast<const float *>(io.llr), io.frames, io.hard, io.iters, io.converged);
-    *name = "spec_r1_f16x2";
+                       (float)cfg.scale, reinterpret_cast<const float *>(io.llr), io.frames, io.hard, io.iters, io.converged,
+                       sp ? *sp : SweepDev{});
+    *name = FUSED ? "fused_spec_r1_f16x2" : "spec_r1_f16x2";
     return hipGetLastError();
 }
 
@@ -232,6 +257,29 @@ hipError_t launch_spec_half(int spec_id, const ldpc_decode_config &cfg, const La
         if constexpr (HalfLayout<CODE, SLOTS>::OK) {                                               \
             *supported = true;                                                                     \
             return launch_r1h<CODE, SLOTS>(cfg, io, num_cus, name);                                \
+        }                                                                                          \
+        return hipSuccess;                                                                         \
+    }                                                                                              \
+    ++id;
+    LDPC_FOR_EACH_SPEC_CODE(LDPC_LAUNCH)
+#undef LDPC_LAUNCH
+    return hipSuccess;
+}
+
+// The same rule as one launch of channel + decode + error accounting (ldpc_sweep_batch), for the codes
+// whose pair of staged frames fits beside the decoder's state.
+hipError_t launch_spec_half_fused(int spec_id, const ldpc_decode_config &cfg, const Launch &io, const SweepDev &sp,
+                                  int num_cus, const char **name, bool *supported)
+{
+    *supported = false;
+    if (cfg.rule != LDPC_RULE_R1) return hipSuccess;
+    int id = 0;
+#define LDPC_LAUNCH(CODE, SLOTS)                                                                   \
+    if (spec_id == id) {                                                                           \
+        if constexpr (HalfLayout<CODE, SLOTS>::OK && (CODE::NB * CODE::Z) % 4 == 0 &&              \
+                      HalfLayout<CODE, SLOTS>::LDS_BYTES + 10 * SLOTS * CODE::NB * CODE::Z <= 64 * 1024) { \
+            *supported = true;                                                                     \
+            return launch_r1h<CODE, SLOTS, true>(cfg, io, num_cus, name, &sp);                     \
         }                                                                                          \
         return hipSuccess;                                                                         \
     }                                                                                              \

@@ -747,8 +747,8 @@ extern "C" int32_t ldpc_sweep_batch(ldpc_code *c, const ldpc_decode_config *cfg,
     if (int rc = check_cfg(cfg)) return rc;
     if (!ch) return fail(LDPC_ERR_ARG, "channel is NULL");
     if (frames < 0) return fail(LDPC_ERR_ARG, "negative frame count");
-    if (compute_dtype == LDPC_F16) return fail(LDPC_ERR_UNSUPPORTED, "no fused sweep in half precision; use the three calls");
-    if (compute_dtype != LDPC_F32 && compute_dtype != LDPC_F64) return fail(LDPC_ERR_ARG, "dtype must be LDPC_F32 or LDPC_F64");
+    if (compute_dtype != LDPC_F32 && compute_dtype != LDPC_F64 && compute_dtype != LDPC_F16)
+        return fail(LDPC_ERR_ARG, "dtype must be LDPC_F32, LDPC_F64 or LDPC_F16");
     if (!counters_dev) return fail(LDPC_ERR_ARG, "NULL buffer");
     if (ref_dev && ref_stride != 0 && ref_stride != c->n) return fail(LDPC_ERR_ARG, "ref_stride must be 0 or n");
     if (ref_dev && (reinterpret_cast<uintptr_t>(ref_dev) & 3u)) return fail(LDPC_ERR_ARG, "ref_dev must be 4-byte aligned");
@@ -770,8 +770,10 @@ extern "C" int32_t ldpc_sweep_batch(ldpc_code *c, const ldpc_decode_config *cfg,
     sp.counters = reinterpret_cast<unsigned long long *>(counters_dev);
     Launch io{nullptr, LDPC_F32, (long long)frames, nullptr, nullptr, nullptr, nullptr, reinterpret_cast<hipStream_t>(stream)};
     bool supported = false;
-    hipError_t e = launch_spec_fused(c->spec_id, *cfg, compute_dtype, io, sp, c->num_cus, c->workspace_for(io.stream),
-                                     &g_kernel, &supported);
+    hipError_t e = compute_dtype == LDPC_F16
+                       ? launch_spec_half_fused(c->spec_id, *cfg, io, sp, c->num_cus, &g_kernel, &supported)
+                       : launch_spec_fused(c->spec_id, *cfg, compute_dtype, io, sp, c->num_cus, c->workspace_for(io.stream),
+                                           &g_kernel, &supported);
     if (e != hipSuccess) return fail(LDPC_ERR_HIP, "fused sweep launch: %s", hipGetErrorString(e));
     if (!supported)
         return fail(LDPC_ERR_UNSUPPORTED, "no fused sweep kernel for this code, rule and arithmetic; "

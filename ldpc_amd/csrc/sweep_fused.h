@@ -165,6 +165,9 @@ inline ChannelDev make_channel_dev(double sigma2, double gain, int plus_is_bit, 
 hipError_t launch_spec_fused(int spec_id, const ldpc_decode_config &cfg, int compute_dtype, const Launch &io,
                              const SweepDev &sp, int num_cus, Scratch &workspace, const char **kernel_name,
                              bool *supported);
+// decode_spec_h.hip: rule R1 in packed half precision
+hipError_t launch_spec_half_fused(int spec_id, const ldpc_decode_config &cfg, const Launch &io, const SweepDev &sp,
+                                  int num_cus, const char **kernel_name, bool *supported);
 hipError_t launch_spec_lnms_fused(int spec_id, const ldpc_decode_config &cfg, int compute_dtype, const Launch &io,
                                   const SweepDev &sp, int num_cus, Scratch &workspace, const char **kernel_name,
                                   bool *supported);

@@ -46,6 +46,23 @@ def test_fused_counters_equal_three_launches(name, rule, snr, frames):
                 assert 0 < fused[1] < frames, fused        # the batch straddles the waterfall
 
 
+@pytest.mark.parametrize("frames", [40_001, 7])
+def test_fused_half_precision_counters_equal_three_launches(frames):
+    """Rule R1 in packed half precision (two frames per lane): the fused launch stages both frames of
+    a lane's pair; counters equal the three launches, odd frame counts included."""
+    import torch
+    dev = torch.device("cuda", 0)
+    code = codes.load_packaged("ccsds512")
+    G = codes.load_packaged_generator("ccsds512")
+    for cfg in (config.R1, config.R1.with_(max_iters=6, early_exit=False)):
+        kernel, fused, three = _both(code, G, cfg, -0.75, frames, np.float16, dev)
+        assert kernel == "fused_spec_r1_f16x2", kernel
+        assert fused.tolist() == three.tolist(), (cfg.early_exit, fused, three)
+        assert fused[0] == frames
+        if cfg.early_exit and frames > 1000:
+            assert 0 < fused[1] < frames, fused
+
+
 def test_fused_with_prefix_doppler_and_all_zero_word():
     import torch
     from ldpc_amd import channel, sweep

@@ -22,6 +22,7 @@ dev = torch.device("cuda", 0)
 lg = int(sys.argv[1]) if len(sys.argv) > 1 else 28
 out = {}
 cases = [("ccsds512", "R1", np.float32, [0.0, 0.5, 1.0, 1.5, 2.0, 2.5, 3.0], 1 << lg, 30),
+         ("ccsds512", "R1", np.float16, [0.0, 0.5, 1.0, 1.5, 2.0, 2.5, 3.0], 1 << lg, 30),   # packed half precision, the same frames
          ("ccsds512", "R1", np.float64, [1.0, 2.0], 1 << (lg - 2), 30),
          ("nr_bg1_z384", "LNMS", np.float32, [-4.0, -3.75, -3.5, -3.25], 1 << (lg - 7), 20)]
 for name, rule, dtype, snrs, frames, iters in cases:
