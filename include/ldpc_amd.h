@@ -332,7 +332,8 @@ int32_t ldpc_rate_recover(const ldpc_rate_match_config *cfg, const void *llr_dev
  * calls in a row add for the same arguments.  ref_dev: transmitted codewords [frames, n]
  * (ref_stride = n), one codeword for all frames (ref_stride = 0) or NULL (the all-zero codeword);
  * 4-byte aligned.  Served for the compiled-in codes (rules R0, R1, OMS on the small ones, LNMS on
- * all); LDPC_ERR_UNSUPPORTED otherwise, and the three calls are the fallback.
+ * all, in LDPC_F32 / LDPC_F64; rule R1 on the small ones in LDPC_F16); LDPC_ERR_UNSUPPORTED
+ * otherwise, and the three calls are the fallback.
  */
 typedef struct ldpc_channel_config {
     double sigma2;                 /* noise variance, 1 / (2 * 10^(SNR/10)), ldpc.py:245 */
