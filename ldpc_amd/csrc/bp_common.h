@@ -1,5 +1,7 @@
 // Shared host/device declarations of the decoder library (gfx950 only).
 #pragma once
+#include <cstdio>
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -115,6 +117,9 @@ inline hipError_t kernel_setup(const void *kernel, int threads, size_t lds, int 
         int nb = 0;
         e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, threads, lds);
         if (e != hipSuccess) return e;
+        if (getenv("LDPC_DEBUG_OCCUPANCY"))
+            fprintf(stderr, "kernel %p: %d threads, %zu B dynamic LDS: %d workgroups per CU by the runtime's count\n",
+                    kernel, threads, lds, nb);
         it = cache.emplace(key, nb).first;
     }
     if (per_cu) *per_cu = it->second;
