@@ -142,6 +142,41 @@ def test_r0_iteration_zero_float_check_on_gpu():
         assert list(r.iters) == [0, 0, 0]
 
 
+def test_r0_iteration_zero_float_check_against_oracle(c_oracle):
+    """`numpy.dot(H, llr) % 2 == 0` on float LLRs (ldpc.py:158,165): the kernels test "finite and an even
+    integer" without fmod; integer-valued, half-integer, huge and tiny LLRs against the CPU restatement
+    (which calls fmod) on every kernel family, in both arithmetic types."""
+    from ldpc_amd.decoder import Decoder
+    rng = np.random.default_rng(77)
+    for name in ("ccsds512", "wifi648", "nr_bg2_z40_r1400"):
+        code = codes.load_packaged(name)
+        dec = Decoder(code)
+        L = np.zeros((12, code.n))
+        L[0] = 2.0 * rng.integers(-3, 4, code.n)             # every row sum even: passes at iteration 0
+        L[1] = L[0]; L[1, 5] += 1.0                           # one odd entry: the rows through it fail
+        L[2] = rng.integers(-3, 4, code.n)                    # integer sums of either parity
+        L[3] = 0.5 * rng.integers(-6, 7, code.n)              # half-integer sums
+        L[4] = 2.0 ** 60 * rng.integers(-2, 3, code.n)        # beyond 2^53 every float is an even integer
+        L[5] = 2.0 ** 24 * rng.integers(-2, 3, code.n)
+        L[6] = 1e-30 * rng.integers(-2, 3, code.n)            # tiny sums: even only when exactly zero
+        L[7] = 4.0
+        L[8] = -2.0
+        L[9] = 3.0                                            # row sums 3 * degree
+        L[10] = 0.0
+        L[11] = 2.0 * rng.integers(-3, 4, code.n); L[11, code.n - 1] = 0.25
+        L = L.astype(np.float32).astype(np.float64)
+        eh, ei, ec, _ = c_oracle.c_decode(code, config.R0, L)
+        assert ei[0] == 0 and ec[0] and ei[7] == 0 and ei[10] == 0 and ei[1] > 0
+        for kernel in (0, 1, 2):
+            for dtype in (np.float64, np.float32):
+                r = dec.decode(L.astype(dtype), config.R0, kernel=kernel, compute_dtype=dtype)
+                zero_pass = ei == 0
+                assert np.array_equal(r.iters == 0, zero_pass), (name, kernel, dtype, r.iters, ei)
+                assert np.array_equal(r.hard[zero_pass], eh[zero_pass]), (name, kernel, dtype)
+                if dtype is np.float64:
+                    assert np.array_equal(r.iters, ei) and np.array_equal(r.converged, ec) and np.array_equal(r.hard, eh)
+
+
 def test_edge_cases_of_the_abi():
     from ldpc_amd import _lib
     from ldpc_amd.decoder import Decoder
