@@ -23,7 +23,24 @@ namespace ldpc {
 template <class C, typename T, int F>
 struct SpaLayout {
     static constexpr int THREADS = ((F * C::Z + 63) / 64) * 64;
-    static constexpr int MSG_BYTES = C::EB * C::Z * (int)sizeof(T);
+    // edges of shift 0 connect a check and a variable of the same lane: their message lives in a
+    // register of that lane (ml[]) and has no place in LDS; row(e) = place of edge e (check order) in msg
+    static constexpr bool LOCAL = spec_local_edges<C>();
+    static constexpr bool local(int e) { return LOCAL && C::row_shift[e] == 0; }
+    static constexpr int row(int e)
+    {
+        int k = 0;
+        for (int i = 0; i < e; ++i) k += !local(i);
+        return k;
+    }
+    static constexpr int reg(int e)  // index of a local edge among the local edges
+    {
+        int k = 0;
+        for (int i = 0; i < e; ++i) k += local(i);
+        return k;
+    }
+    static constexpr int NLOCAL = reg(C::EB);
+    static constexpr int MSG_BYTES = row(C::EB) * C::Z * (int)sizeof(T);
     static constexpr int SLOT_BYTES = ((MSG_BYTES + 127) / 128) * 128 + (F > 1 ? 32 : 0);
     static constexpr int LDS_BYTES = F * SLOT_BYTES;
 };
@@ -57,6 +74,7 @@ spec_spa_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t 
         const long long frame = grp * F + f;
         const bool active = lane_on && frame < frames;
         T L[NB], own[NB];
+        T ml[LY::NLOCAL > 0 ? LY::NLOCAL : 1];  // messages of the lane-local edges
         unsigned long long hm[NB];
         if constexpr (PREFETCH) __builtin_amdgcn_s_waitcnt(0);  // the staged LLRs have landed
         static_for<0, NB>([&](auto bc) {
@@ -69,7 +87,8 @@ spec_spa_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t 
             hm[bc] = __ballot(!(l > (T)0));
             static_for<0, D>([&](auto k) {  // bpsk.py:299-306: every edge starts with the channel LLR
                 constexpr int e = C::col_slot[k0 + k], s = C::col_shift[k0 + k];
-                if (lane_on) *reinterpret_cast<T *>(msg_b + e * Z * ST + rot_bwd<Z, ST, s>(zb)) = l;  // idle lanes alias lane 0
+                if constexpr (LY::local(e)) ml[LY::reg(e)] = l;
+                else if (lane_on) *reinterpret_cast<T *>(msg_b + LY::row(e) * Z * ST + rot_bwd<Z, ST, s>(zb)) = l;  // idle lanes alias lane 0
             });
         });
         if constexpr (PREFETCH) {
@@ -97,7 +116,14 @@ spec_spa_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t 
                 static_for<0, MB>([&](auto br) {
                     constexpr int e0 = C::row_ptr[br], D = C::row_ptr[br + 1] - e0;
                     T v[D > 0 ? D : 1];
-                    static_for<0, D>([&](auto p) { v[p] = *reinterpret_cast<const T *>(msg_b + (e0 + p) * Z * ST + zb); });
+                    static_for<0, D>([&](auto p) {
+                        if constexpr (LY::local(e0 + p)) v[p] = ml[LY::reg(e0 + p)];
+                        else v[p] = *reinterpret_cast<const T *>(msg_b + LY::row(e0 + p) * Z * ST + zb);
+                    });
+                    auto put = [&](auto p, T m) {
+                        if constexpr (LY::local(e0 + p)) ml[LY::reg(e0 + p)] = m;
+                        else *reinterpret_cast<T *>(msg_b + LY::row(e0 + p) * Z * ST + zb) = m;
+                    };
                     if constexpr (RULE == 2 || RULE == 3) {  // bpsk.py:325-339, channel.py:471-474
                         T th[D > 0 ? D : 1], suf[D > 0 ? D : 1];
                         static_for<0, D>([&](auto p) { th[p] = spa_tanh_half(v[p], g.clip_tanh_arg); });
@@ -105,8 +131,7 @@ spec_spa_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t 
                         static_for<0, D>([&](auto pp) { constexpr int p = D - 1 - pp; suf[p] = run; run *= th[p]; });
                         T pre = (T)1;
                         static_for<0, D>([&](auto p) {
-                            *reinterpret_cast<T *>(msg_b + (e0 + p) * Z * ST + zb) =
-                                spa_message(pre * suf[p], g.clip_prod, g.scale, RULE == 3);
+                            put(p, spa_message(pre * suf[p], g.clip_prod, g.scale, RULE == 3));
                             pre *= th[p];
                         });
                     } else {  // channel.py:332-352
@@ -121,7 +146,7 @@ spec_spa_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t 
                         T pre = (T)0;
                         static_for<0, D>([&](auto p) {
                             const bool negative = (__popc(neg & ~(1u << p)) & 1) != 0;
-                            *reinterpret_cast<T *>(msg_b + (e0 + p) * Z * ST + zb) = phi_message(pre + suf[p], negative);
+                            put(p, phi_message(pre + suf[p], negative));
                             pre += ph[p];
                         });
                     }
@@ -133,8 +158,9 @@ spec_spa_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t 
                     unsigned off[D > 0 ? D : 1];
                     static_for<0, D>([&](auto k) {
                         constexpr int e = C::col_slot[k0 + k], s = C::col_shift[k0 + k];
-                        off[k] = e * Z * ST + rot_bwd<Z, ST, s>(zb);
-                        r[k] = *reinterpret_cast<const T *>(msg_b + off[k]);
+                        off[k] = LY::row(e) * Z * ST + rot_bwd<Z, ST, s>(zb);
+                        if constexpr (LY::local(e)) r[k] = ml[LY::reg(e)];
+                        else r[k] = *reinterpret_cast<const T *>(msg_b + off[k]);
                     });
                     bool sw[D > 0 ? D : 1];
                     static_for<0, (D > 0 ? D - 1 : 0)>([&](auto k) {
@@ -160,7 +186,11 @@ spec_spa_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t 
                             qn[k + 1] = sw[k] ? a : b;
                         }
                     });
-                    static_for<0, D>([&](auto k) { *reinterpret_cast<T *>(msg_b + off[k]) = qn[k]; });
+                    static_for<0, D>([&](auto k) {
+                        constexpr int e = C::col_slot[k0 + k];
+                        if constexpr (LY::local(e)) ml[LY::reg(e)] = qn[k];
+                        else *reinterpret_cast<T *>(msg_b + off[k]) = qn[k];
+                    });
                     T b = L[bc] + run;
                     if (g.clip_post > (T)0) b = clip(b, -g.clip_post, g.clip_post);
                     own[bc] = b;
