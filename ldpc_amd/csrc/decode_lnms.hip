@@ -440,10 +440,9 @@ lnms_body(const Cfg<T> &g, const TL *__restrict__ llr, long long frames, uint8_t
 // One copy of the code per wave of a slot where a slot is a whole number of waves (NR BG1 Z = 384: six)
 // and the workgroup has several; every wave executes the same barriers in the same order in its own copy.
 // A switch for kernel experiments, off by default: measured on BG1 in float it removes 9.4 % of the
-// vector instructions (28 600 instead of 31 600 per frame-sweep) and not a microsecond of the run
-// time (the waiting share of the wave cycles grows from 37 % to 42 %): the twelve waves of a workgroup
-// move from barrier to barrier together, and what a layer costs is its chain of dependent instructions
-// and LDS round trips, not the number of instructions issued beside it.
+// vector instructions (28 600 instead of 31 600 per frame-sweep) and nothing of the run time (the
+// waiting share of the wave cycles grows from 37 % to 42 %): six copies are about 230 KB of code
+// streamed once per sweep, against a 64 KB instruction cache that the single copy fits.
 #ifndef LDPC_LNMS_WAVE_COPIES
 #define LDPC_LNMS_WAVE_COPIES 0
 #endif
