@@ -11,6 +11,10 @@ from ldpc_amd.decoder import Decoder
 dev = torch.device("cuda", 0)
 cases = [("wifi648", 1 << 21, 2, [0.5, 1.0, 1.5, 2.0]), ("nr_bg2_z40", 1 << 19, 2, [-4.5, -4.0, -3.5]),
          ("nr_bg1_z384", 1 << 15, 2, [-3.6, -3.5, -3.25])]
+tag = ""
+if len(sys.argv) > 2 and sys.argv[1] == "bg1":   # python tools/lnms_half_deep.py bg1 CHUNKS: the long code only, CHUNKS x 2^15 frames per point
+    cases = [("nr_bg1_z384", 1 << 15, int(sys.argv[2]), [-3.6, -3.5, -3.25])]
+    tag = "_bg1"
 out = {}
 for name, frames, chunks, snrs in cases:
     code = codes.load_packaged(name); dec = Decoder(code)
@@ -36,4 +40,4 @@ for name, frames, chunks, snrs in cases:
                "both_converged_to_different_words": differ}
         out[f"{name}@{snr}"] = rec
         print(name, snr, json.dumps(rec), flush=True)
-json.dump(out, open(os.path.join(ROOT, "gpurun_out", "lnms_half_deep.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(ROOT, "gpurun_out", f"lnms_half_deep{tag}.json"), "w"), indent=1)
