@@ -2,6 +2,7 @@
 """Throughput of the batched LDPC decoder on MI355X: decoded info Gbit/s at 10 BP iterations.
 
     python bench.py --gpus 1 --steps 10 --warmup 2
+    python bench.py --gpus N ...         (starts its N ranks itself, one per GPU, through torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One step = one decode launch over a batch of synthetic frames resident in HBM.  Frames are
@@ -222,6 +223,40 @@ def cpu_baseline(code, cfg, batch, k_info, dtype, seconds, cpu_sample=0):
             "gpu_results_identical_on_sample": bool(same) if exact else None}
 
 
+def launch_plan(gpus, env, argv, script=None, device_count=None, port=None):
+    """What `bench.py --gpus N` does with the process it was started as.
+
+    ("run", world, rank, local): this process is one rank (WORLD_SIZE names the job, set by
+    torch.distributed.run) or the whole one-GPU job.  ("spawn", cmd): started plainly with
+    --gpus N > 1 — the ranks do not exist yet, so this process (which must not have touched the GPU)
+    starts `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>` and relays
+    its exit code; rank 0 of that job prints the JSON line.  A job whose size differs from --gpus,
+    or (under RCCL, one rank per GPU) exceeds the GPUs of the node, is an error rather than a
+    silently smaller run."""
+    if gpus < 1:
+        raise SystemExit(f"bench.py: --gpus {gpus}: need at least one GPU")
+    backend = env.get("LDPC_BENCH_BACKEND", "nccl")
+    if backend == "nccl" and device_count is not None and gpus > device_count:
+        raise SystemExit(f"bench.py: --gpus {gpus} but this node shows {device_count} GPU(s); one rank per GPU under RCCL "
+                         f"(LDPC_BENCH_BACKEND=gloo rehearses the launch with every rank on GPU 0)")
+    if "WORLD_SIZE" in env:
+        world = int(env["WORLD_SIZE"])
+        if world != gpus:
+            raise SystemExit(f"bench.py: --gpus {gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {gpus} "
+                             f"(or run `python bench.py --gpus {gpus}` plainly, which starts the ranks itself)")
+        return ("run", world, int(env.get("RANK", "0")), int(env.get("LOCAL_RANK", "0")))
+    if gpus == 1:
+        return ("run", 1, 0, 0)
+    if port is None:
+        import socket
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), script or os.path.abspath(__file__)] + list(argv)
+    return ("spawn", cmd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -245,12 +280,16 @@ def main():
     ap.add_argument("--no-other", action="store_true", help="headline workload only (no bg1, no other)")
     args = ap.parse_args()
 
-    import torch
+    import torch   # importing torch and counting devices does not initialise HIP
+    if torch.cuda.device_count() == 0:
+        raise SystemExit("bench.py needs an MI355X: the decoder has no CPU path")
+    plan = launch_plan(args.gpus, os.environ, sys.argv[1:], device_count=torch.cuda.device_count())
+    if plan[0] == "spawn":
+        import subprocess
+        raise SystemExit(subprocess.run(plan[1]).returncode)
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    _, world, rank, local = plan
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the decoder has no CPU path")
     # rehearsal on a one-GPU box: LDPC_BENCH_BACKEND=gloo puts every rank on device 0 and runs the
