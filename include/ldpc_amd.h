@@ -82,6 +82,14 @@ extern "C" {
 #define LDPC_KERNEL_AUTO 0 /* circulant kernel when the code has QC structure, else edge-list   */
 #define LDPC_KERNEL_CSR 1  /* generic edge-list kernel                                          */
 #define LDPC_KERNEL_QC 2   /* circulant kernel (error if the handle carries no QC structure)    */
+/*
+ * LDPC_RULE_LNMS only: the kernel compiled per 5G NR base graph, with lifting size, shift table and
+ * number of active block rows as run-time arguments.  Chosen by LDPC_KERNEL_AUTO for every handle
+ * whose circulant description is a prefix of the block rows of BG1 or BG2 (any Z up to 384, any
+ * shifts) unless the exact table is compiled in; this selector forces it (error if the handle does
+ * not match a base graph).
+ */
+#define LDPC_KERNEL_GRAPH 3
 
 /*
  * The constants the reference edits in its source, per rule (presets: ldpc_amd/config.py):
@@ -99,10 +107,17 @@ extern "C" {
  *                     (ldpc.py:158,165: numpy.dot(H, llr) % 2 == 0).
  *   num_active_checks R0: rows [0, k) take part in the check-node update (self.m, ldpc.py:30,175);
  *                     the syndrome always uses every row.  -1 = all.
+ *                     LDPC_RULE_LNMS: the decoder sees the sub-matrix of rows [0, k) ONLY (sweeps,
+ *                     syndrome test and the meaning of "degree one"): what 5G rate matching leaves
+ *                     of the matrix when extension parity bits were not sent (the reference cuts
+ *                     the matrix by hand, /root/reference/channel.py:35).  Variables in none of
+ *                     those rows decide from their channel LLR.  k must be a whole number of block
+ *                     rows of a handle that matches an NR base graph (LDPC_KERNEL_GRAPH).
  *   num_refresh_vars  R1-R4: variables [0, k) refresh their variable-to-check messages
  *                     (range(self.n), bpsk.py:244); -1 = all.
  *                     (Both bounds are served by the table-driven circulant kernels and the
- *                     edge-list kernel; layered min-sum and the half-precision mode refuse them.)
+ *                     edge-list kernel; the half-precision mode refuses them, layered min-sum all but the
+ *                     block-row prefix above.)
  *   offset            LDPC_RULE_OMS only: the offset beta (no counterpart in the reference).
  */
 typedef struct ldpc_decode_config {

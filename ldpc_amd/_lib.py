@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("LDPC_AMD_LIB") or os.path.join(_HERE, "libldpc_amd.so
 
 LDPC_OK, LDPC_ERR_ARG, LDPC_ERR_HIP, LDPC_ERR_UNSUPPORTED, LDPC_ERR_NO_DEVICE = range(5)
 F32, F64 = 0, 1
-KERNEL_AUTO, KERNEL_CSR, KERNEL_QC = 0, 1, 2
+KERNEL_AUTO, KERNEL_CSR, KERNEL_QC, KERNEL_GRAPH = 0, 1, 2, 3
 
 #: every symbol include/ldpc_amd.h declares
 SYMBOLS = ["ldpc_last_error", "ldpc_abi_version", "ldpc_device_count", "ldpc_code_create_csr",

@@ -28,6 +28,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 UNITS = [(f"decode_spec_spaw_r{k}.o", "decode_spec_spaw.hip", [f"-DLDPC_SPAW_RULE={k}"]) for k in (2, 3, 4)]
 UNITS += [("decode_spec_spa.o", "decode_spec_spa.hip", []),
           ("decode_lnms.o", "decode_lnms.hip", []),
+          ("decode_lnms_rt.o", "decode_lnms_rt.hip", []),
           ("decode_lnms_fused.o", "decode_lnms.hip", ["-DLDPC_SPEC_FUSED"]),
           ("decode_spec_fused.o", "decode_spec.hip", ["-DLDPC_SPEC_FUSED"]),
           ("decode_spec_r1w_r1.o", "decode_spec_r1w.hip", ["-DLDPC_R1W_RULE=1"]),
@@ -51,7 +52,7 @@ HEADERS = ["bp_common.h", "extra_kernels.h", "sweep_fused.h", "bp_math.h", "spec
 
 
 #: source files each kernel family is built from (for stamping counter profiles)
-KERNEL_SOURCES = {"spec_lnms_f16x2": ["decode_lnms_h.hip", "lnms_plan.h", "half2_ops.h"], "spec_lnms": ["decode_lnms.hip", "lnms_plan.h"], "spec_r0w": ["decode_spec_r1w.hip", "spec_r1w_plan.h"],
+KERNEL_SOURCES = {"spec_lnms_f16x2": ["decode_lnms_h.hip", "lnms_plan.h", "half2_ops.h"], "spec_lnms": ["decode_lnms.hip", "lnms_plan.h"], "bg_lnms": ["decode_lnms_rt.hip", "lnms_plan.h"], "spec_r0w": ["decode_spec_r1w.hip", "spec_r1w_plan.h"],
                   "spec_r1w": ["decode_spec_r1w.hip", "spec_r1w_plan.h"], "spec_spaw": ["decode_spec_spaw.hip", "spec_r1w_plan.h"],
                   "spec_spa": ["decode_spec_spa.hip"], "spec_r0": ["decode_spec.hip"], "spec_r1": ["decode_spec.hip"],
                   "spec_oms": ["decode_spec.hip"], "spec_r1_f16x2": ["decode_spec_h.hip", "half2_ops.h"], "spec_omsw": ["decode_spec_r1w.hip", "spec_r1w_plan.h"], "qc_lnms": ["decode_qc_lnms.hip"], "qc_r0": ["decode_qc_r0.hip"],

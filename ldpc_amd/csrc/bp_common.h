@@ -13,13 +13,11 @@
 
 namespace ldpc {
 
-constexpr int kMaxCheckDegree = 64;
+constexpr int kMaxCheckDegree = 64;  // sign bits of one check are kept in one 64-bit mask
 // bytes of the file-scope device array behind ldpc_decode_batch_noalloc (held per GPU until the process ends)
 #ifndef LDPC_NOALLOC_SCRATCH_BYTES
 #define LDPC_NOALLOC_SCRATCH_BYTES (32u << 20)
 #endif
-static_assert(true, "");
-constexpr int kUnused = 0;  // sign bits of one check are kept in one 64-bit mask
 
 // Edge lists on the device (all int32).
 struct CsrDev {
@@ -166,6 +164,18 @@ LDPC_DECL_SPAW(2) LDPC_DECL_SPAW(3) LDPC_DECL_SPAW(4)
 // decode_qc_lnms.hip: the same rule for any circulant code, base graph in device tables
 hipError_t launch_qc_lnms(const QcDev &code, const ldpc_decode_config &cfg, int compute_dtype, const Launch &io,
                           int num_cus, Scratch &workspace, const char **kernel_name, bool *supported);
+// decode_lnms_rt.hip: the same rule compiled per NR base graph (connectivity only); lifting size, shift
+// table and the number of active block rows are run-time arguments.  A handle whose circulant
+// description is a prefix of the block rows of such a graph carries the kernel's tables.
+struct BgHandle {
+    int graph = -1;  // which base graph; -1: none
+    int Z = 0, mb = 0, nb = 0;
+    unsigned *d_tab = nullptr;
+};
+int bg_graph_match(int Z, int mb, int nb, int Eb, const int *er, const int *ec);
+hipError_t bg_tables_create(int graph, int Z, int mb, const int *es, unsigned **d_tab);
+hipError_t launch_bg_lnms(const BgHandle &h, int mb_act, const ldpc_decode_config &cfg, int compute_dtype,
+                          const Launch &io, int num_cus, const char **kernel_name, bool *supported);
 // count_errors.hip
 hipError_t launch_count_errors(const uint8_t *hard, const uint8_t *ref, long long ref_stride,
                                const int *iters, const uint8_t *conv, long long frames, int n,

@@ -51,6 +51,7 @@ struct ldpc_code {
     int spec_id = -1;       // compiled-in specialisation of this code, if any
     QcDev qc{};
     int *d_qc = nullptr;    // one allocation: row_ptr | row_info | col_ptr | col_info
+    BgHandle bg;            // run-time tables of the base-graph layered kernel, if the description matches one
     // scratch of the kernels that keep frame state in global memory, one buffer per stream a decode
     // was enqueued on: launches on different streams may run at the same time and must not share slices
     std::vector<std::pair<hipStream_t, Scratch>> workspaces;
@@ -259,6 +260,12 @@ extern "C" int32_t ldpc_code_attach_qc(ldpc_code *c, int32_t mb, int32_t nb, int
     c->qc.max_dc = max_dc; c->qc.max_dv = max_dv;
     c->has_qc = true;
     c->spec_id = spec_match(Z, mb, nb, Eb, er, ec, es);
+    if (c->bg.d_tab) { (void)hipFree(c->bg.d_tab); c->bg = BgHandle{}; }
+    const int graph = c->qc_pairs ? -1 : bg_graph_match(Z, mb, nb, Eb, er, ec);
+    if (graph >= 0) {
+        HIP_TRY(bg_tables_create(graph, Z, mb, es, &c->bg.d_tab));
+        c->bg.graph = graph; c->bg.Z = Z; c->bg.mb = mb; c->bg.nb = nb;
+    }
     return LDPC_OK;
 }
 
@@ -267,6 +274,7 @@ extern "C" int32_t ldpc_code_destroy(ldpc_code *c)
     if (!c) return LDPC_OK;
     if (c->d_ints) (void)hipFree(c->d_ints);
     if (c->d_qc) (void)hipFree(c->d_qc);
+    if (c->bg.d_tab) (void)hipFree(c->bg.d_tab);
     for (auto &w : c->workspaces)
         if (w.second.ptr) (void)hipFree(w.second.ptr);
     if (c->host_stage) (void)hipFree(c->host_stage);
@@ -307,7 +315,7 @@ static int decode_impl(ldpc_code *c, const ldpc_decode_config *cfg, const void *
     if ((llr_dtype != LDPC_F32 && llr_dtype != LDPC_F64) ||
         (compute_dtype != LDPC_F32 && compute_dtype != LDPC_F64 && compute_dtype != LDPC_F16))
         return fail(LDPC_ERR_ARG, "llr_dtype must be LDPC_F32 or LDPC_F64, compute_dtype LDPC_F32, LDPC_F64 or LDPC_F16");
-    if (kernel < LDPC_KERNEL_AUTO || kernel > LDPC_KERNEL_QC) return fail(LDPC_ERR_ARG, "unknown kernel selector %d", kernel);
+    if (kernel < LDPC_KERNEL_AUTO || kernel > LDPC_KERNEL_GRAPH) return fail(LDPC_ERR_ARG, "unknown kernel selector %d", kernel);
     if (frames == 0) { g_kernel = "none"; return LDPC_OK; }
     if (!llr_dev || !hard_dev || !iters_dev || !converged_dev) return fail(LDPC_ERR_ARG, "NULL buffer");
     HIP_TRY(hipSetDevice(c->device));
@@ -349,17 +357,39 @@ static int decode_impl(ldpc_code *c, const ldpc_decode_config *cfg, const void *
     const bool quirks = (cfg->rule == 0 && cfg->num_active_checks >= 0 && cfg->num_active_checks < c->m) ||
                         (cfg->rule != 0 && cfg->num_refresh_vars >= 0 && cfg->num_refresh_vars < c->n);
     if (kernel == LDPC_KERNEL_QC && !c->has_qc) return fail(LDPC_ERR_ARG, "no QC description attached to this code");
-    if (cfg->rule == LDPC_RULE_LNMS && (quirks || (cfg->num_active_checks >= 0 && cfg->num_active_checks < c->m) || cfg->clip_post > 0.0))
-        return fail(LDPC_ERR_UNSUPPORTED, "layered min-sum has no num_active_checks / num_refresh_vars / clip_post");
+    if (kernel == LDPC_KERNEL_GRAPH && (cfg->rule != LDPC_RULE_LNMS || c->bg.graph < 0))
+        return fail(LDPC_ERR_ARG, "the base-graph kernel serves layered min-sum on handles whose circulant description is a "
+                                  "row prefix of an NR base graph");
+    if (cfg->rule == LDPC_RULE_LNMS && (quirks || cfg->clip_post > 0.0))
+        return fail(LDPC_ERR_UNSUPPORTED, "layered min-sum has no num_refresh_vars / clip_post");
+    // layered min-sum on the first num_active_checks rows: the decoder sees that sub-matrix only (what 5G
+    // rate matching leaves of the matrix); served by the base-graph kernel for whole block rows
+    int lnms_rows = -1;
+    if (cfg->rule == LDPC_RULE_LNMS && cfg->num_active_checks >= 0 && cfg->num_active_checks < c->m) {
+        if (c->bg.graph < 0 || cfg->num_active_checks % c->bg.Z != 0 || (kernel != LDPC_KERNEL_AUTO && kernel != LDPC_KERNEL_GRAPH))
+            return fail(LDPC_ERR_UNSUPPORTED, "layered min-sum takes num_active_checks only as a whole number of block rows, on a "
+                                              "handle whose circulant description is a row prefix of an NR base graph");
+        lnms_rows = cfg->num_active_checks / c->bg.Z;
+    }
     // the compiled-in R1 kernels carry no posterior clip (the reference's R1 has none, bpsk.py:235-237)
     const bool spec_ok = !((cfg->rule == LDPC_RULE_R1 || cfg->rule == LDPC_RULE_OMS) && cfg->clip_post > 0.0);
-    if (kernel == LDPC_KERNEL_AUTO && c->has_qc && !quirks && c->spec_id >= 0 && spec_ok) {
+    if (kernel == LDPC_KERNEL_AUTO && c->has_qc && !quirks && c->spec_id >= 0 && spec_ok && lnms_rows < 0) {
         bool supported = false;
         hipError_t e = launch_spec(c->spec_id, *cfg, compute_dtype, io, c->num_cus, &g_kernel, &supported);
         if (e != hipSuccess) return fail(LDPC_ERR_HIP, "specialised kernel launch: %s", hipGetErrorString(e));
         if (supported) return LDPC_OK;
     }
     if (cfg->rule == LDPC_RULE_LNMS) {
+        if ((kernel == LDPC_KERNEL_AUTO || kernel == LDPC_KERNEL_GRAPH) && c->bg.graph >= 0) {
+            bool supported = false;
+            hipError_t e = launch_bg_lnms(c->bg, lnms_rows < 0 ? c->bg.mb : lnms_rows, *cfg, compute_dtype, io, c->num_cus,
+                                          &g_kernel, &supported);
+            if (e != hipSuccess) return fail(LDPC_ERR_HIP, "base-graph layered kernel launch: %s", hipGetErrorString(e));
+            if (supported) return LDPC_OK;
+            if (kernel == LDPC_KERNEL_GRAPH || lnms_rows >= 0)
+                return fail(LDPC_ERR_UNSUPPORTED, "the base-graph layered kernel needs the core block rows active, a lifting size "
+                                                  "of at most 768 (384 in double) and float LLRs for float arithmetic");
+        }
         if (kernel != LDPC_KERNEL_CSR && c->has_qc && !c->qc_pairs) {
             bool supported = false;
             hipError_t e = launch_qc_lnms(c->qc, *cfg, compute_dtype, io, c->num_cus, ws, &g_kernel, &supported);

@@ -364,14 +364,33 @@ def numpy_decode_lnms(code, cfg, llr, dtype=np.float64):
     return hard_out, iters, conv, post_out.astype(np.float64)
 
 
+def row_prefix_lists(code, rows: int):
+    """Edge lists (row_ptr, col_idx, col_ptr, csc_edge) of the first ``rows`` checks of ``code`` on all
+    of its n columns: the matrix a layered decode with num_active_checks = rows sees."""
+    E = int(code.row_ptr[rows])
+    row_ptr = np.asarray(code.row_ptr[:rows + 1], np.int32)
+    col_idx = np.asarray(code.col_idx[:E], np.int32)
+    order = np.argsort(col_idx, kind="stable")     # by column; rows ascend inside a column
+    col_ptr = np.zeros(code.n + 1, np.int32)
+    np.cumsum(np.bincount(col_idx, minlength=code.n), out=col_ptr[1:])
+    return row_ptr, col_idx, col_ptr, order.astype(np.int32)
+
+
 def c_decode_lnms(code, cfg, llr, nthreads: int = 0, use_float: bool = False, want_posterior: bool = True):
+    """cfg.num_active_checks in [0, m): the decode runs on the sub-matrix of those rows (sweeps, syndrome
+    and variable degrees), as LDPC_RULE_LNMS defines it in include/ldpc_amd.h."""
     lib = _load_c()
     L = np.ascontiguousarray(np.array(llr, dtype=np.float64, ndmin=2))
     B, n = L.shape
     assert n == code.n
-    arrs = [np.ascontiguousarray(a, dtype=np.int32) for a in
-            (code.row_ptr, code.col_idx, code.col_ptr, code.csc_edge)]
-    ccode = _OracleCode(code.m, code.n, code.num_edges, *[a.ctypes.data for a in arrs])
+    m, E = code.m, code.num_edges
+    lists = (code.row_ptr, code.col_idx, code.col_ptr, code.csc_edge)
+    if 0 <= cfg.num_active_checks < code.m:
+        m = int(cfg.num_active_checks)
+        lists = row_prefix_lists(code, m)
+        E = int(lists[0][m])
+    arrs = [np.ascontiguousarray(a, dtype=np.int32) for a in lists]
+    ccode = _OracleCode(m, code.n, E, *[a.ctypes.data for a in arrs])
     ccfg = _OracleCfg(int(cfg.rule), int(cfg.max_iters), int(bool(cfg.early_exit)), 0, -1, -1,
                       float(cfg.scale), 0.0, 0.0, 0.0)
     hard = np.zeros((B, n), np.uint8)

@@ -143,7 +143,8 @@ def test_table_driven_layered_kernel_matches_oracle(name, c_oracle):
 @pytest.mark.gpu
 def test_layered_on_a_base_graph_that_is_not_compiled_in(c_oracle):
     """A caller's own table: BG1 connectivity with other shift coefficients and a smaller lifting
-    size takes the table-driven layered kernel automatically."""
+    size takes the base-graph kernel automatically (connectivity compiled in, shifts and lifting size at
+    run time); the table-driven kernel, forced, gives the same."""
     from ldpc_amd import nr_bg1
     from ldpc_amd.decoder import Decoder
     for Z, seed in ((384, 5), (96, 6)):
@@ -154,7 +155,10 @@ def test_layered_on_a_base_graph_that_is_not_compiled_in(c_oracle):
         L = ((2 * (1.0 + np.sqrt(s2) * rng.standard_normal((48, code.n)))) / s2).astype(np.float32).astype(np.float64)
         eh, ei, ec, ep = c_oracle.c_decode_lnms(code, config.LNMS, L, use_float=True)
         res = dec.decode(L.astype(np.float32), config.LNMS, compute_dtype=np.float32, want_posterior=True)
-        assert res.kernel.startswith("qc_lnms")
+        assert res.kernel == "bg_lnms_f32"
         assert np.array_equal(res.iters, ei) and np.array_equal(res.converged, ec)
         assert np.array_equal(res.hard, eh) and np.array_equal(res.posterior.astype(np.float64), ep)
         assert ec.sum() > 0
+        res = dec.decode(L.astype(np.float32), config.LNMS, compute_dtype=np.float32, want_posterior=True, kernel=2)
+        assert res.kernel.startswith("qc_lnms")
+        assert np.array_equal(res.iters, ei) and np.array_equal(res.hard, eh) and np.array_equal(res.posterior.astype(np.float64), ep)

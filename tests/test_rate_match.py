@@ -174,6 +174,7 @@ def test_rate_matched_link_with_retransmission():
     act = codes.compile_qc(rm.active_submatrix(qc, r0.rows_needed()), "bg1_z96_active")
     buf = r0.recover_device(llr0, n_act, filler_llr=40.0)
     a = Decoder(act).decode(buf.cpu().numpy(), cfg, compute_dtype=np.float32)
+    assert a.kernel == "bg_lnms_f32"   # the rate-matched sub-matrix runs on the base-graph kernel, not on the table-driven one
     ref = cw.cpu().numpy()
     ok1 = a.converged & (a.hard[:, :K] == ref[:, :K]).all(axis=1)
     # second transmission: more rows become active, the first buffer is widened and combined into
@@ -184,6 +185,7 @@ def test_rate_matched_link_with_retransmission():
     r2.recover_device(llr2, n2, 40.0, into=wide)
     act2 = codes.compile_qc(rm.active_submatrix(qc, (n2 - K) // Z), "bg1_z96_active2")
     b = Decoder(act2).decode(wide.cpu().numpy(), cfg, compute_dtype=np.float32)
+    assert b.kernel == "bg_lnms_f32"
     ok2 = b.converged & (b.hard[:, :K] == ref[:, :K]).all(axis=1)
     assert 0.02 < 1 - ok1.mean() < 0.98, ok1.mean()               # one transmission: in the waterfall
     assert ok2.mean() > 0.999 and ok2.sum() > ok1.sum()

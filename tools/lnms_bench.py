@@ -7,9 +7,10 @@ sys.path.insert(0, ROOT)
 from ldpc_amd import codes, config, sweep
 from ldpc_amd.decoder import Decoder
 dev = torch.device("cuda", 0)
-KERNEL = 2 if "qc" in sys.argv[1:] else 0   # "qc": the table-driven layered kernel instead of the compiled-in one
+# "qc": the table-driven layered kernel instead of the compiled-in one; "graph": the base-graph kernel (run-time shifts)
+KERNEL = 2 if "qc" in sys.argv[1:] else 3 if "graph" in sys.argv[1:] else 0
 dtypes = [a for a in sys.argv[1:] if a in ("f32", "f64")] or ["f32", "f64"]
-names = [a for a in sys.argv[1:] if a not in ("f32", "f64", "qc")] or ["nr_bg1_z384", "nr_bg2_z40", "nr_bg2_z40_r1400", "wifi648"]
+names = [a for a in sys.argv[1:] if a not in ("f32", "f64", "qc", "graph")] or ["nr_bg1_z384", "nr_bg2_z40", "nr_bg2_z40_r1400", "wifi648"]
 for name in names:
     code = codes.load_packaged(name); dec = Decoder(code); k = code.n - code.m
     frames = 16384 if code.n > 4096 else 1 << 18
