@@ -28,7 +28,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 UNITS = [(f"decode_spec_spaw_r{k}.o", "decode_spec_spaw.hip", [f"-DLDPC_SPAW_RULE={k}"]) for k in (2, 3, 4)]
 UNITS += [("decode_spec_spa.o", "decode_spec_spa.hip", []),
           ("decode_lnms.o", "decode_lnms.hip", []),
-          ("decode_lnms_rt.o", "decode_lnms_rt.hip", []),
+          ("decode_lnms_rt_bg1.o", "decode_lnms_rt.hip", ["-DLDPC_BG_GRAPH=0"]),
+          ("decode_lnms_rt_bg2.o", "decode_lnms_rt.hip", ["-DLDPC_BG_GRAPH=1"]),
           ("decode_lnms_fused.o", "decode_lnms.hip", ["-DLDPC_SPEC_FUSED"]),
           ("decode_spec_fused.o", "decode_spec.hip", ["-DLDPC_SPEC_FUSED"]),
           ("decode_spec_r1w_r1.o", "decode_spec_r1w.hip", ["-DLDPC_R1W_RULE=1"]),
