@@ -17,8 +17,9 @@ frame converges as `worst_case_early_exit`.
 
 Rank 0 prints one JSON line.  Beside the headline it carries
   roofline      algorithmic HBM bytes per launch / measured kernel time, against 8 TB/s
-  lds_roofline  algorithmic LDS bytes of the executed iterations against the LDS rates of the
-                instruction widths involved
+  lds_roofline  measured: share of the time the LDS arrays were busy (counter pass on file, only while the
+                kernel source is unchanged since); beside it the LDS bytes the formulation moves per
+                executed iteration against the LDS rates of the instruction widths involved
   valu_roofline vector instructions issued (counter pass on file, only while the kernel source is
                 unchanged since) against the nominal issue rate
   cpu_baseline  the CPU restatement (oracle/bp_oracle.c, OpenMP) timed on a bounded sample of the
@@ -80,7 +81,7 @@ def _profile_record(kind, key, fixed, kernel):
 def rooflines(code, cfg, dtype, frames, kernel_ms, executed, kernel, code_name, rule_name, fused=False):
     """HBM, LDS and vector-issue rooflines of one launch."""
     itemsize = {"f64": 8, "f32": 4, "f16": 2}[dtype]
-    key = f"{code_name}/{rule_name}/{dtype}/" + ("fused" if fused else "f32llr")
+    key = f"{code_name}/{rule_name}/{dtype}/" + ("fused" if fused else "f32llr") + ("/graph" if kernel.startswith("bg_lnms") else "")
     fixed = not cfg.early_exit
     sec = kernel_ms * 1e-3
     # decode: f32 LLR in, u8 hard + i32 + u8 out; fused sweep: the transmitted codeword (u8) in, nothing out
@@ -93,17 +94,30 @@ def rooflines(code, cfg, dtype, frames, kernel_ms, executed, kernel, code_name, 
             "kernel": kernel, "kernel_ms": kernel_ms, "bytes_per_frame": per_frame}
     roof["frac"] = roof["achieved"] / roof["peak"]
     rd, wr = lds_bytes_per_frame_iter(code, cfg.rule, itemsize)
-    floor = executed * (rd / ((LDS_READ64_GBS if itemsize == 8 else LDS_READ32_GBS) * 1e9) + wr / (LDS_WRITE_GBS * 1e9))
-    lds = {"bound": "lds", "achieved": (rd + wr) * executed / sec / 1e9, "unit": "GB/s",
-           "read_bytes_per_frame_iter": rd, "write_bytes_per_frame_iter": wr,
-           "rates_gb_s": {"read": LDS_READ64_GBS if itemsize == 8 else LDS_READ32_GBS, "write": LDS_WRITE_GBS}}
-    lds["peak"] = (rd + wr) * executed / floor / 1e9      # rate at which this read/write mix could move at best
-    lds["frac"] = lds["achieved"] / lds["peak"]
     qc = getattr(code, "qc", None)
+    kept = 0.0
     if qc is not None and qc.mb <= 4 and kernel.startswith(("spec_r0_", "spec_r1_", "spec_oms_", "fused_spec_")):
         # the single-wave kernels keep edges of shift 0 inside the lane (registers): that share of the
-        # algorithmic edge traffic above never reaches LDS
-        lds["edge_share_kept_in_registers"] = float((qc.edge_shift == 0).mean())
+        # algorithmic edge traffic never reaches LDS and is not counted as moved
+        kept = float((qc.edge_shift == 0).mean())
+    rd, wr = rd * (1.0 - kept), wr * (1.0 - kept)
+    read_rate = LDS_READ64_GBS if itemsize == 8 else LDS_READ32_GBS
+    floor = executed * (rd / (read_rate * 1e9) + wr / (LDS_WRITE_GBS * 1e9))
+    lds = {"bound": "lds", "achieved": (rd + wr) * executed / sec / 1e9, "unit": "GB/s",
+           "read_bytes_per_frame_iter": rd, "write_bytes_per_frame_iter": wr, "edge_share_kept_in_registers": kept,
+           "rates_gb_s": {"read": read_rate, "write": LDS_WRITE_GBS}}
+    lds["peak"] = (rd + wr) * executed / floor / 1e9      # rate at which this read/write mix could move at best
+    lds["frac_by_formula"] = lds["achieved"] / lds["peak"]
+    # measured: LDS-array cycles (SQ_LDS_IDX_ACTIVE, bank conflicts included) over the cycles the compute
+    # units were busy, from the counter pass on file for this kernel source
+    lc = _profile_record("lds_counters", key, fixed, kernel)
+    if lc:
+        lds.update({"measured_busy_frac": lc["lds_array_busy_frac"],
+                    "lds_array_cycles_per_frame_iteration": lc["lds_array_cycles_per_frame_iteration"],
+                    "lds_instructions_per_frame_iteration": lc["lds_instructions_per_frame_iteration"],
+                    "bank_conflict_share_of_lds_cycles": lc["SQ_LDS_BANK_CONFLICT"] / max(lc["SQ_LDS_IDX_ACTIVE"], 1.0),
+                    "source": lc["source"]})
+    lds["frac"] = lds.get("measured_busy_frac", lds["frac_by_formula"])
     out = {"roofline": roof, "lds_roofline": lds}
     sq = _profile_record("sq_counters", key, fixed, kernel)
     if sq:

@@ -19,8 +19,11 @@ dst = os.path.join(ROOT, "profiles")
 WORKLOADS = {"ccsds_r0_f64": "ccsds512/R0/f64/f32llr", "ccsds_r0_f64_fused": "ccsds512/R0/f64/fused",
              "ccsds_r0_f64_ee": "ccsds512/R0/f64/f32llr/early_exit", "bg1_lnms_f32": "nr_bg1_z384/LNMS/f32/f32llr",
              "bg1_lnms_f64": "nr_bg1_z384/LNMS/f64/f32llr", "bg1_lnms_f16": "nr_bg1_z384/LNMS/f16/f32llr",
+             "bg1_bglnms_f32": "nr_bg1_z384/LNMS/f32/f32llr/graph", "bg1_bglnms_f64": "nr_bg1_z384/LNMS/f64/f32llr/graph",
+             "ccsds_R3_f32": "ccsds512/R3/f32/f32llr", "ccsds_R3_f64": "ccsds512/R3/f64/f32llr", "ccsds_R1_f64": "ccsds512/R1/f64/f32llr",
              "bg2_R0_f64": "nr_bg2_z40/R0/f64/f32llr", "bg2_R0_f32": "nr_bg2_z40/R0/f32/f32llr",
-             "bg2_R1_f32": "nr_bg2_z40/R1/f32/f32llr", "bg2_R3_f32": "nr_bg2_z40/R3/f32/f32llr"}
+             "bg2_R1_f64": "nr_bg2_z40/R1/f64/f32llr", "bg2_R1_f32": "nr_bg2_z40/R1/f32/f32llr",
+             "bg2_R3_f32": "nr_bg2_z40/R3/f32/f32llr", "bg2_R3_f64": "nr_bg2_z40/R3/f64/f32llr"}
 # only the workloads this tag's run covered
 WORKLOADS = {wl: key for wl, key in WORKLOADS.items()
              if os.path.isdir(os.path.join(src, f"stats_{wl}")) or os.path.isdir(os.path.join(src, f"fetch_{wl}"))}
@@ -94,6 +97,39 @@ for wl, key in WORKLOADS.items():
                  "kernel_source_sha16": kernel_source_digest(bench["config"]["kernel"]),
                  "valu_wave_instructions_per_frame_iteration": mean["SQ_INSTS_VALU"] / executed})
     sq["workloads"][key] = mean
+# LDS activity of the decode kernel (one more pass), per dispatch
+lds = {"note": "rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_LDS_LOAD "
+               "SQ_INSTS_LDS_STORE SQ_BUSY_CU_CYCLES SQ_WAIT_INST_LDS over the same bench command; sums over the device per "
+               "dispatch of the decode kernel (mean over its dispatches).  SQ_LDS_IDX_ACTIVE = LDS-array cycles (bank "
+               "conflicts included), SQ_BUSY_CU_CYCLES = cycles a compute unit had waves: their ratio is the share of the "
+               "time the LDS arrays were busy.",
+       "workloads": {}}
+for wl, key in WORKLOADS.items():
+    path = os.path.join(src, f"lds_{wl}", "t_counter_collection.csv")
+    if not os.path.exists(path):
+        continue
+    per = {}
+    for r in csv.DictReader(open(path)):
+        if decoder_kernel(r["Kernel_Name"]):
+            d = per.setdefault(r["Dispatch_Id"], {})
+            d[r["Counter_Name"]] = d.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+    mean = {c: sum(d[c] for d in per.values()) / len(per) for c in next(iter(per.values()))}
+    bench = json.load(open(os.path.join(src, f"lds_{wl}.json")))
+    frames = bench["config"]["frames_per_launch_per_gpu"]
+    executed = bench["counters"]["iterations"] + (0 if not bench["config"]["early_exit"] else bench["counters"]["not_converged"])
+    mean.update({"frames": frames, "executed_frame_iterations": executed, "kernel": bench["config"]["kernel"],
+                 "early_exit": bench["config"]["early_exit"], "kernel_ms": bench["roofline"]["kernel_ms"],
+                 "kernel_source_sha16": kernel_source_digest(bench["config"]["kernel"]),
+                 "lds_array_busy_frac": mean["SQ_LDS_IDX_ACTIVE"] / mean["SQ_BUSY_CU_CYCLES"],
+                 "lds_array_busy_frac_of_kernel_time": mean["SQ_LDS_IDX_ACTIVE"] / (bench["roofline"]["kernel_ms"] * 1e-3 * 2.4e9 * 256),
+                 "lds_array_cycles_per_frame_iteration": mean["SQ_LDS_IDX_ACTIVE"] / executed,
+                 "lds_instructions_per_frame_iteration": mean["SQ_INSTS_LDS"] / executed})
+    lds["workloads"][key] = mean
+if lds["workloads"]:
+    out = os.path.join(dst, f"{tag}_lds_counters.json")
+    json.dump(lds, open(out, "w"), indent=1)
+    print("wrote", out)
+    print(json.dumps(lds["workloads"], indent=1))
 if sq["workloads"]:
     out = os.path.join(dst, f"{tag}_sq_counters.json")
     json.dump(sq, open(out, "w"), indent=1)
