@@ -195,7 +195,9 @@ int32_t ldpc_decode_batch(ldpc_code *code, const ldpc_decode_config *cfg, const 
  * workgroups as it holds slices for.  The call allocates and frees nothing.  A code whose state
  * for one frame exceeds the array is refused with LDPC_ERR_UNSUPPORTED.  Every call on a GPU
  * shares that GPU's array: calls that overlap in time on one GPU (different streams or threads)
- * race; serialise them.
+ * race; serialise them.  The first call per device and kernel looks up the array's address and the
+ * kernel's launch limits (no allocation, but runtime queries): under HIP graph capture make one call
+ * with the same code, rule and arithmetic outside the capture first.
  */
 int32_t ldpc_decode_batch_noalloc(ldpc_code *code, const ldpc_decode_config *cfg, const void *llr_dev,
                                   int32_t llr_dtype, int32_t compute_dtype, int32_t kernel, int64_t frames,
@@ -203,6 +205,13 @@ int32_t ldpc_decode_batch_noalloc(ldpc_code *code, const ldpc_decode_config *cfg
                                   void *posterior_dev, void *stream);
 /* size in bytes of the scratch array behind ldpc_decode_batch_noalloc */
 int64_t ldpc_noalloc_scratch_bytes(void);
+/*
+ * Device memory the handle's growable workspaces hold right now (the kernels that keep frame state in
+ * global memory own one buffer per stream they were launched on, at most eight; each is sized for the
+ * largest batch it has served, not for the device).  No counterpart in the reference; for tests and for
+ * embedders who account for device memory.
+ */
+int64_t ldpc_code_workspace_bytes(const ldpc_code *code);
 
 /*
  * Same, host buffers in and out (allocates device staging, copies, decodes, copies back,
@@ -372,7 +381,8 @@ int32_t ldpc_sweep_batch(ldpc_code *code, const ldpc_decode_config *cfg, const l
  * by side on the device.  The rule, arithmetic and kernel selector are shared.  No counterpart in
  * the reference (it decodes one frame of one code per call, /root/reference/bpsk.py:824,
  * channel.py:845).  Error statistics of all segments can be summed into one counter buffer by
- * calling ldpc_count_errors per segment with the same counters_dev (it adds atomically).
+ * calling ldpc_count_errors per segment with the same counters_dev (it adds atomically).  A segment
+ * that is refused ends the call with its error; the segments before it stay enqueued.
  */
 typedef struct ldpc_segment {
     ldpc_code *code;

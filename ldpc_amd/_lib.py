@@ -20,7 +20,7 @@ KERNEL_AUTO, KERNEL_CSR, KERNEL_QC, KERNEL_GRAPH = 0, 1, 2, 3
 #: every symbol include/ldpc_amd.h declares
 SYMBOLS = ["ldpc_last_error", "ldpc_abi_version", "ldpc_device_count", "ldpc_code_create_csr",
            "ldpc_code_attach_qc", "ldpc_code_destroy", "ldpc_code_info", "ldpc_decode_batch",
-           "ldpc_decode_batch_host", "ldpc_decode_batch_noalloc", "ldpc_noalloc_scratch_bytes", "ldpc_count_errors", "ldpc_allreduce_counters", "ldpc_channel_llr", "ldpc_channel_llr_doppler", "ldpc_decode_segments", "ldpc_sweep_batch", "ldpc_encoder_create", "ldpc_encoder_destroy", "ldpc_encode_batch", "ldpc_encode_random", "ldpc_rate_match", "ldpc_rate_recover",
+           "ldpc_decode_batch_host", "ldpc_decode_batch_noalloc", "ldpc_noalloc_scratch_bytes", "ldpc_code_workspace_bytes", "ldpc_count_errors", "ldpc_allreduce_counters", "ldpc_channel_llr", "ldpc_channel_llr_doppler", "ldpc_decode_segments", "ldpc_sweep_batch", "ldpc_encoder_create", "ldpc_encoder_destroy", "ldpc_encode_batch", "ldpc_encode_random", "ldpc_rate_match", "ldpc_rate_recover",
            "ldpc_last_kernel"]
 
 
@@ -109,6 +109,8 @@ def load() -> ctypes.CDLL:
     lib.ldpc_decode_batch_noalloc.argtypes = lib.ldpc_decode_batch.argtypes
     lib.ldpc_noalloc_scratch_bytes.restype = i64
     lib.ldpc_noalloc_scratch_bytes.argtypes = []
+    lib.ldpc_code_workspace_bytes.restype = i64
+    lib.ldpc_code_workspace_bytes.argtypes = [vp]
     lib.ldpc_decode_batch_host.restype = i32
     lib.ldpc_decode_batch_host.argtypes = [vp, ctypes.POINTER(CDecodeConfig), vp, i32, i32, i32,
                                            i64, vp, vp, vp, vp]

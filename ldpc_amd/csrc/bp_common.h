@@ -8,6 +8,7 @@
 #include <map>
 #include <mutex>
 #include <tuple>
+#include <utility>
 
 #include "ldpc_amd.h"
 
@@ -73,24 +74,31 @@ struct Scratch {
     void *ptr = nullptr;
     size_t bytes = 0;
     bool fixed = false;
+    bool exhausted = false;  // set by scratch_reserve: fixed scratch too small for one slice
 };
-// Make room for `grid` slices of `per_wg` bytes; may lower `grid` (fixed scratch).  Growing
-// frees and allocates, which synchronises the device: the old buffer is idle by then.
+// Make room for `grid` slices of `per_wg` bytes; may lower `grid` (fixed scratch).  The buffer is sized
+// for the batch at hand, not for the largest grid the device could hold (a 40-frame call on a code
+// whose slices are megabytes must not hold gigabytes); it grows geometrically, at most to
+// `want_grid` slices, and never shrinks.  Growing frees and allocates, which synchronises the device:
+// the old buffer is idle by then.
 inline hipError_t scratch_reserve(Scratch &ws, size_t per_wg, long long want_grid, long long &grid)
 {
+    ws.exhausted = false;
     if (ws.fixed) {
         const long long fit = (long long)(ws.bytes / per_wg);
-        if (fit < 1) return hipErrorOutOfMemory;
+        if (fit < 1) { ws.exhausted = true; return hipErrorOutOfMemory; }
         if (grid > fit) grid = fit;
         return hipSuccess;
     }
-    const size_t need = (size_t)want_grid * per_wg;  // sized for the largest grid: no regrowth with the batch size
+    const size_t need = (size_t)grid * per_wg, cap = (size_t)(want_grid > grid ? want_grid : grid) * per_wg;
     if (ws.bytes < need) {
+        size_t take = need > 2 * ws.bytes ? need : 2 * ws.bytes;
+        if (take > cap) take = cap;
         if (ws.ptr) (void)hipFree(ws.ptr);
         ws.ptr = nullptr; ws.bytes = 0;
-        hipError_t e = hipMalloc(&ws.ptr, need);
+        hipError_t e = hipMalloc(&ws.ptr, take);
         if (e != hipSuccess) return e;
-        ws.bytes = need;
+        ws.bytes = take;
     }
     return hipSuccess;
 }
@@ -103,15 +111,22 @@ inline hipError_t kernel_setup(const void *kernel, int threads, size_t lds, int 
 {
     static std::mutex mu;
     static std::map<std::tuple<const void *, int, int, size_t>, int> cache;
+    static std::map<std::pair<const void *, int>, size_t> lds_limit;  // largest dynamic LDS size set per (kernel, device)
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     const auto key = std::make_tuple(kernel, dev, threads, lds);
     std::lock_guard<std::mutex> lock(mu);
-    auto it = cache.find(key);
-    if (it == cache.end()) {
+    // the attribute is one value per kernel, not per launch shape: it is only ever raised, so that a
+    // kernel used with a large and then a small footprint keeps the limit the large one needs
+    size_t &limit = lds_limit[std::make_pair(kernel, dev)];
+    if (lds > limit) {
         e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
+        limit = lds;
+    }
+    auto it = cache.find(key);
+    if (it == cache.end()) {
         int nb = 0;
         e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, threads, lds);
         if (e != hipSuccess) return e;

@@ -109,6 +109,9 @@ encode_dense_kernel(EncDev e, const unsigned long long *__restrict__ taps, const
                 const Philox4 r = philox4x32_10((unsigned)af, (unsigned)(af >> 32), (unsigned)w, 1u, k0, k1);
                 *reinterpret_cast<uint4 *>(rnd + w * 4) = make_uint4(r.x, r.y, r.z, r.w);
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // other lanes read these words below
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
         for (int j = 0; j < e.k_cols; ++j) {
             const long long pos = (long long)j * Z + z;
@@ -116,13 +119,17 @@ encode_dense_kernel(EncDev e, const unsigned long long *__restrict__ taps, const
             if (lane_on) b = msg ? (msg[frame * k + pos] & 1u) : ((rnd[(pos >> 7) * 4 + ((pos >> 5) & 3)] >> (pos & 31)) & 1u);
             const unsigned long long m = __ballot(b != 0);
             const int c = e.info_cols[j];
-            if (z == 0) col_mask[c] = m;
+            if (z == 0) col_mask[c] = m;   // (read by every lane in the steps below: fenced after this loop)
             if (lane_on) {
                 cw[frame * n + (long long)c * Z + z] = (uint8_t)b;
                 if (msg_out) msg_out[frame * k + pos] = (uint8_t)b;
             }
         }
         for (int s = 0; s < e.n_steps; ++s) {
+            // lane 0's column masks of the information columns / of the previous step, before any lane reads them
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             unsigned acc = 0;
             for (int c = 0; c < e.n_cols; ++c) {
                 const unsigned long long t = taps[(size_t)s * e.n_cols + c];  // the same for every lane

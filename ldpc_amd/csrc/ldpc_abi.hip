@@ -61,8 +61,17 @@ struct ldpc_code {
     std::vector<char> host_bounce;  // host side of the small-result copy of ldpc_decode_batch_host
     Scratch &workspace_for(hipStream_t stream)
     {
-        for (auto &w : workspaces)
-            if (w.first == stream) return w.second;
+        for (size_t i = 0; i < workspaces.size(); ++i)
+            if (workspaces[i].first == stream) {
+                if (i + 1 != workspaces.size()) std::swap(workspaces[i], workspaces.back());  // most recent last
+                return workspaces.back().second;
+            }
+        // a caller that creates and destroys streams must not grow the list without bound: beyond eight
+        // streams the buffer of the one used longest ago goes (hipFree waits for the device first)
+        if (workspaces.size() >= 8) {
+            if (workspaces.front().second.ptr) (void)hipFree(workspaces.front().second.ptr);
+            workspaces.erase(workspaces.begin());
+        }
         workspaces.emplace_back(stream, Scratch{});
         return workspaces.back().second;
     }
@@ -343,7 +352,7 @@ static int decode_impl(ldpc_code *c, const ldpc_decode_config *cfg, const void *
     if (noalloc)
         if (int rc = noalloc_scratch(c->device, &fixed_ws)) return rc;
     Scratch &ws = noalloc ? fixed_ws : c->workspace_for(io.stream);
-    auto scratch_full = [&](hipError_t e) { return noalloc && e == hipErrorOutOfMemory; };
+    auto scratch_full = [&](hipError_t e) { return noalloc && e == hipErrorOutOfMemory && ws.exhausted; };
     const char *too_big = "one frame's state exceeds the %zu bytes of scratch of the allocation-free entry point; use ldpc_decode_batch";
     if (cfg->rule == LDPC_RULE_BF) {  // hard-decision bit flipping: its own kernel, any matrix
         if (posterior_dev) return fail(LDPC_ERR_UNSUPPORTED, "bit flipping has no posteriors: pass posterior_dev = NULL");
@@ -441,6 +450,14 @@ extern "C" int32_t ldpc_decode_batch_noalloc(ldpc_code *c, const ldpc_decode_con
 }
 
 extern "C" int64_t ldpc_noalloc_scratch_bytes(void) { return (int64_t)kNoallocScratchBytes; }
+
+extern "C" int64_t ldpc_code_workspace_bytes(const ldpc_code *c)
+{
+    if (!c) return 0;
+    size_t total = 0;
+    for (const auto &w : c->workspaces) total += w.second.bytes;
+    return (int64_t)total;
+}
 
 extern "C" int32_t ldpc_decode_batch_host(ldpc_code *c, const ldpc_decode_config *cfg, const void *llr,
                                           int32_t llr_dtype, int32_t compute_dtype, int32_t kernel,
@@ -674,7 +691,11 @@ extern "C" int32_t ldpc_encoder_create(int32_t Z, int32_t n_cols, int32_t nb, in
                 m ^= 1ull << term_shift[t];  // a shift listed twice cancels, as it does in the XOR of the terms
             }
         if (pairs > 0 && n_terms >= 4 * pairs) {
-            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&enc->d_taps), taps.size() * sizeof(unsigned long long)));
+            e = hipMalloc(reinterpret_cast<void **>(&enc->d_taps), taps.size() * sizeof(unsigned long long));
+            if (e != hipSuccess) {
+                (void)hipFree(enc->d_ints);
+                return fail(LDPC_ERR_HIP, "encoder tap masks: %s", hipGetErrorString(e));
+            }
             e = hipMemcpy(enc->d_taps, taps.data(), taps.size() * sizeof(unsigned long long), hipMemcpyHostToDevice);
             if (e != hipSuccess) {
                 (void)hipFree(enc->d_taps);

@@ -212,7 +212,7 @@ __device__ __forceinline__ void llr_prefetch(float *stage, const float *llr, lon
         const float *from = src + bc * C::Z;
         const unsigned to = base + bc * 256u;
         asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off"
-                     :: "v"(from), "s"(to) : "memory");  // M0 is reserved: the compiler reloads it before each use of its own
+                     :: "v"(from), "s"(to) : "memory", "m0");
     });
 }
 template <class C, int F>
@@ -227,7 +227,7 @@ __device__ __forceinline__ void llr_prefetch_frame(float *stage, const float *ll
         const float *from = src + bc * C::Z;
         const unsigned to = base + bc * 256u;
         asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off"
-                     :: "v"(from), "s"(to) : "memory");
+                     :: "v"(from), "s"(to) : "memory", "m0");
     });
 }
 

@@ -73,6 +73,10 @@ class Decoder:
         except Exception:
             pass
 
+    def workspace_bytes(self) -> int:
+        """Device memory the handle's growable workspaces hold (kernels with frame state in global memory)."""
+        return int(self._lib.ldpc_code_workspace_bytes(self._h))
+
     # ------------------------------------------------------------------ host arrays
     def decode(self, llr: np.ndarray, cfg: DecodeConfig, compute_dtype=np.float64,
                want_posterior: bool = False, kernel: int = _lib.KERNEL_AUTO) -> DecodeResult:

@@ -156,7 +156,8 @@ def decode_mixed(parts, cfg: DecodeConfig, compute_dtype=np.float64, kernel: int
     """Decode one batch that mixes frames of several codes: ``parts`` is a list of
     (Decoder, DeviceBatch), one per code; a single ``ldpc_decode_segments`` call enqueues every part
     on a stream of its own, so the codes are decoded side by side.  With ``counters`` (an int64[5]
-    device tensor) the error statistics of all parts are added into it.  Returns the kernel names."""
+    device tensor) the error statistics of all parts are added into it.  Returns the name of the kernel
+    the last part ran on."""
     import ctypes
 
     import torch
@@ -181,7 +182,6 @@ def decode_mixed(parts, cfg: DecodeConfig, compute_dtype=np.float64, kernel: int
     ccfg = CDecodeConfig.from_config(cfg)
     _lib.check(lib.ldpc_decode_segments(segs, len(parts), ctypes.byref(ccfg), 0 if llr_dtype == torch.float32 else 1,
                                         _dtype_code(compute_dtype), kernel))
-    names = []
     for i, (dec, bt) in enumerate(parts):
         if counters is not None:
             dec.count_errors_device(bt.hard.data_ptr(), bt.ref.data_ptr(), dec.code.n, bt.iters.data_ptr(),

@@ -109,6 +109,15 @@ def test_flooding_rules_on_bg1_through_the_global_workspace(c_oracle):
         res = dec.decode(Lr, cfg, want_posterior=True)
         assert res.kernel.startswith("csr_global")
         assert np.array_equal(res.iters, ei) and np.array_equal(res.hard, eh) and np.array_equal(res.posterior, ep)
+    # the workspace is sized for the batch (8 frames of about 2.4 MB of messages), not for every workgroup
+    # the device could hold (some 5 GB for this code)
+    assert 8 * 2 * code.num_edges * 8 <= dec.workspace_bytes() <= 64 << 20
+    L2 = np.tile(L, (6, 1))
+    res = dec.decode(L2, config.R1.with_(max_iters=2), want_posterior=False)      # a larger batch grows it ...
+    grown = dec.workspace_bytes()
+    assert 48 * 2 * code.num_edges * 8 <= grown <= 256 << 20
+    dec.decode(L, config.R1.with_(max_iters=2))                                   # ... and a smaller one keeps it
+    assert dec.workspace_bytes() == grown
 
 
 @pytest.mark.gpu

@@ -90,6 +90,12 @@ def test_mixed_ccsds_and_5g_batch(rule, c_oracle):
         same = (ei == iters[:k]) & (ec == conv[:k]) & (eh == hard[:k]).all(axis=1)
         assert same.mean() >= 0.99, (name, same.mean())
         assert conv.mean() > 0.5, (name, conv.mean())
+        # ... and strictly against the numpy restatement, the one pinned to the reference's own methods
+        # (numpy's tanh / arctanh, as bpsk.py:325-339 and channel.py:471-474 call them): flags, iteration
+        # counts and words identical on every frame
+        k = 256
+        nh, ni, nc, _ = bp_oracle.numpy_decode(dec.code, cfg, bt.llr[:k].cpu().numpy().astype(np.float64))
+        assert np.array_equal(ni, iters[:k]) and np.array_equal(nc, conv[:k]) and np.array_equal(nh, hard[:k]), name
     assert counters.cpu().numpy().tolist() == total.tolist()
     assert total[1] > 0 and total[3] > 0
 
