@@ -153,6 +153,8 @@ LDPC_DECL_QC(0) LDPC_DECL_QC(1) LDPC_DECL_QC(2) LDPC_DECL_QC(3) LDPC_DECL_QC(4) 
 int spec_match(int Z, int mb, int nb, int Eb, const int *er, const int *ec, const int *es);
 hipError_t launch_spec(int spec_id, const ldpc_decode_config &cfg, int compute_dtype, const Launch &io,
                        int num_cus, const char **kernel_name, bool *supported);
+hipError_t launch_spec_bounded(int spec_id, const ldpc_decode_config &cfg, int compute_dtype, const Launch &io,
+                               int num_cus, const char **kernel_name, bool *supported);
 // decode_spec_h.hip: rule R1 in packed half precision, two frames per lane (compute_dtype LDPC_F16)
 hipError_t launch_spec_half(int spec_id, const ldpc_decode_config &cfg, const Launch &io, int num_cus,
                             const char **kernel_name, bool *supported);

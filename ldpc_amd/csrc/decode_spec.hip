@@ -43,9 +43,12 @@ struct SpecLayout {
 // where the check states of a lane fit registers (LOCAL, base graphs of at most four block rows)
 // such an edge's posterior comes from the lane's own register and its check state goes back the
 // same way (`cl`), and only the rotated edges go through LDS.  The values are the same either way.
-template <class C, typename T, bool FLOATCHK>
+// ACT: only the checks below `mact` take part in the update (int(self.m) of the constructor, ldpc.py:30,175:
+// ccsds.py:18 builds LDPCEncoder(4, 8, 16), i.e. 8 rows); the others send zeros.  The syndrome uses every row.
+template <class C, typename T, bool FLOATCHK, bool ACT = false>
 __device__ __forceinline__ int spec_r0_checks(const unsigned char *post_b, unsigned char *cs_b, unsigned zb, unsigned zp,
-                                              const T (&own)[C::NB], typename SNum<T>::Pair (&cl)[spec_local_edges<C>() ? C::MB : 1])
+                                              const T (&own)[C::NB], typename SNum<T>::Pair (&cl)[spec_local_edges<C>() ? C::MB : 1],
+                                              int z = 0, int mact = 0)
 {
     typedef typename SNum<T>::Pair Pair;
     constexpr int Z = C::Z, MB = C::MB, ST = sizeof(T), SP = 2 * sizeof(T);
@@ -66,6 +69,9 @@ __device__ __forceinline__ int spec_r0_checks(const unsigned char *post_b, unsig
             if constexpr (FLOATCHK) fsum += b;
         });
         if constexpr (D < 2) { m1 = (T)0; m2 = (T)0; }  // ldpc.py:178
+        if constexpr (ACT) {
+            if (br * Z + z >= mact) { m1 = (T)0; m2 = (T)0; }
+        }
         const Pair cst = SNum<T>::make(SNum<T>::with_sign(m1, sx), SNum<T>::with_sign(m2, sx));
         *reinterpret_cast<Pair *>(cs_b + br * Z * SP + zp) = cst;
         if constexpr (LOCAL) cl[br] = cst;
@@ -89,7 +95,7 @@ __device__ __forceinline__ int spec_r0_checks(const unsigned char *post_b, unsig
 // Registers: for the small base graphs (CCSDS) at least three waves per SIMD in double and four in
 // float, as the single-wave workgroups are sized for (a few registers more would silently cost a
 // wave per SIMD); larger graphs take what they need.
-template <class C, typename T, typename TL, int F, bool FUSED = false>
+template <class C, typename T, typename TL, int F, bool FUSED = false, bool ACT = false>
 __global__ void __launch_bounds__((SpecLayout<C, T, F>::THREADS))
 #if LDPC_SPEC_WAVES > 0
 LDPC_SPEC_OCC
@@ -190,8 +196,8 @@ spec_r0_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *
             const bool float_check = t == 0 && g.float_syndrome0 && g.early_exit;
             int bad = 0;
             if (!done) {
-                bad = float_check ? spec_r0_checks<C, T, true>(post_b, cs_b, zb, zp, own, cl)
-                                  : spec_r0_checks<C, T, false>(post_b, cs_b, zb, zp, own, cl);
+                bad = float_check ? spec_r0_checks<C, T, true, ACT>(post_b, cs_b, zb, zp, own, cl, z, g.num_active_checks)
+                                  : spec_r0_checks<C, T, false, ACT>(post_b, cs_b, zb, zp, own, cl, z, g.num_active_checks);
             }
             // ---- does every check of my slot hold?
             bool slot_ok;
@@ -522,9 +528,13 @@ static hipError_t launch_spec_r0(const ldpc_decode_config &cfg, const Launch &io
     static_assert(LY::LDS_BYTES <= 160 * 1024, "LDS limit");
     Cfg<T> g;
     g.rule = 0; g.max_iters = cfg.max_iters; g.early_exit = cfg.early_exit;
-    g.float_syndrome0 = cfg.float_syndrome0; g.num_active_checks = -1; g.num_refresh_vars = -1;
+    const bool bounded = !kFused && cfg.num_active_checks >= 0 && cfg.num_active_checks < C::MB * C::Z;
+    g.float_syndrome0 = cfg.float_syndrome0; g.num_active_checks = bounded ? cfg.num_active_checks : -1; g.num_refresh_vars = -1;
     g.scale = (T)cfg.scale; g.clip_tanh_arg = (T)0; g.clip_prod = (T)0; g.clip_post = (T)0; g.offset = (T)0;
     auto k = spec_r0_kernel<C, T, TL, F, kFused>;
+    if constexpr (!kFused) {
+        if (bounded) k = spec_r0_kernel<C, T, TL, F, false, true>;
+    }
     int per_cu = 0;
     hipError_t e = kernel_setup(reinterpret_cast<const void *>(k), LY::THREADS, LY::LDS_BYTES, &per_cu);
     if (e != hipSuccess) return e;
@@ -637,6 +647,27 @@ int spec_match(int Z, int mb, int nb, int Eb, const int *er, const int *ec, cons
     LDPC_FOR_EACH_SPEC_CODE(LDPC_MATCH)
 #undef LDPC_MATCH
     return -1;
+}
+
+// The reference's loop bounds (num_active_checks under R0, num_refresh_vars under R1-R4) on the compiled-in
+// kernels that carry them as template switches: the single-wave R0 kernel, and the multi-wave R1 and
+// sum-product kernels of the large base graphs.  supported = false: the table-driven kernels serve the call.
+hipError_t launch_spec_bounded(int spec_id, const ldpc_decode_config &cfg, int compute_dtype, const Launch &io,
+                               int num_cus, const char **name, bool *supported)
+{
+    *supported = false;
+    if (cfg.rule == 1) return launch_spec_r1w(spec_id, cfg, compute_dtype, io, num_cus, name, supported);
+    if (cfg.rule == 2) return launch_spec_spaw_rule_2(spec_id, cfg, compute_dtype, io, num_cus, name, supported);
+    if (cfg.rule == 3) return launch_spec_spaw_rule_3(spec_id, cfg, compute_dtype, io, num_cus, name, supported);
+    if (cfg.rule == 4) return launch_spec_spaw_rule_4(spec_id, cfg, compute_dtype, io, num_cus, name, supported);
+    if (cfg.rule != 0) return hipSuccess;
+    int id = 0;
+#define LDPC_LAUNCH(CODE, SLOTS)                                                                   \
+    if (spec_id == id) return launch_spec_code<CODE, SLOTS>(cfg, compute_dtype, io, num_cus, name, supported, nullptr); \
+    ++id;
+    LDPC_FOR_EACH_SPEC_CODE(LDPC_LAUNCH)
+#undef LDPC_LAUNCH
+    return hipSuccess;
 }
 
 hipError_t launch_spec(int spec_id, const ldpc_decode_config &cfg, int compute_dtype, const Launch &io,

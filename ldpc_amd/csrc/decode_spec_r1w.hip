@@ -31,7 +31,10 @@ struct R1wLayout {
     static constexpr int LDS_BYTES = FLAG_OFF + 64;
 };
 
-template <class C, typename T, typename TL, int F, int W, bool OMS>  // OMS: the offset rule (LDPC_RULE_OMS) instead of R1's
+// REF: the refresh loop of the reference runs over range(self.n), the CONSTRUCTOR's n (bpsk.py:244,
+// channel.py:241): variables from g.num_refresh_vars on keep sending their channel value.  A switch of
+// its own so that the plain kernel does not pay the comparison and the selects.
+template <class C, typename T, typename TL, int F, int W, bool OMS, bool REF = false>  // OMS: the offset rule (LDPC_RULE_OMS) instead of R1's
 __global__ void __launch_bounds__(64 * W * ((F * C::Z + 63) / 64))
 spec_r1w_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__restrict__ hard_out,
                 int *__restrict__ iters_out, uint8_t *__restrict__ conv_out, T *__restrict__ post_out)
@@ -177,9 +180,12 @@ spec_r1w_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t 
                                         qn[k + 1] = sw[k] ? a : b;
                                     }
                                 });
+                                bool refresh = true;
+                                if constexpr (REF) refresh = bc * Z + z < g.num_refresh_vars;
                                 static_for<0, D>([&](auto k) {
-                                    q[q0 + k] = qn[k];
-                                    *reinterpret_cast<T *>(qv_b + (k0 + k) * Z * ST + zb) = qn[k];
+                                    const T qw = refresh ? qn[k] : L[j];
+                                    q[q0 + k] = qw;
+                                    *reinterpret_cast<T *>(qv_b + (k0 + k) * Z * ST + zb) = qw;
                                 });
                                 own[j] = L[j] + run;  // bpsk.py:237
                                 hb_b[bc * Z + z1] = (uint8_t)hard_bit<1>(own[j]);
@@ -218,7 +224,7 @@ spec_r1w_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t 
 // Every wave tracks all slots' iteration counters and queue positions as uniform values (they
 // follow from the syndrome flags every wave reads), so the loop ends for all waves together when
 // the last queue is empty.  Same arithmetic as spec_r1w_kernel; g.early_exit != 0, max_iters >= 1.
-template <class C, typename T, typename TL, int F, int W, bool OMS>  // OMS: the offset rule (LDPC_RULE_OMS) instead of R1's
+template <class C, typename T, typename TL, int F, int W, bool OMS, bool REF = false>  // OMS, REF: as above
 __global__ void __launch_bounds__(64 * W * ((F * C::Z + 63) / 64))
 spec_r1w_slots_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__restrict__ hard_out,
                       int *__restrict__ iters_out, uint8_t *__restrict__ conv_out, T *__restrict__ post_out)
@@ -365,9 +371,12 @@ spec_r1w_slots_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, ui
                                     qn[k + 1] = sw[k] ? a : b;
                                 }
                             });
+                            bool refresh = true;
+                            if constexpr (REF) refresh = bc * Z + z < g.num_refresh_vars;
                             static_for<0, D>([&](auto k) {
-                                q[q0 + k] = qn[k];
-                                *reinterpret_cast<T *>(qv_b + (k0 + k) * Z * ST + zb) = qn[k];
+                                const T qw = refresh ? qn[k] : L[j];
+                                q[q0 + k] = qw;
+                                *reinterpret_cast<T *>(qv_b + (k0 + k) * Z * ST + zb) = qw;
                             });
                             own[j] = L[j] + run;  // bpsk.py:237
                             hb_b[bc * Z + z1] = (uint8_t)hard_bit<1>(own[j]);
@@ -603,18 +612,35 @@ constexpr int packed_slots()
 #endif
 constexpr bool kOms = LDPC_R1W_RULE == 6;  // this translation unit builds the offset rule instead of R1
 
+// The refresh bound is built for rule R1 on the large base graphs (the reference's own call shape is its
+// 5G matrix under a constructor n of 648, channel.py:646); elsewhere the table-driven kernels serve it.
+template <class C>
+constexpr bool r1w_refresh_built() { return !kOms && C::EB > 100; }
+
 template <class C, typename T, typename TL, int F, int W>
-static hipError_t launch_r1w(const ldpc_decode_config &cfg, const Launch &io, int num_cus, const char **name)
+static hipError_t launch_r1w(const ldpc_decode_config &cfg, const Launch &io, int num_cus, const char **name, bool *supported)
 {
     typedef R1wLayout<C, T, F> LY;
     constexpr int G = (LY::LANES + 63) / 64;
+    const bool bounded = cfg.num_refresh_vars >= 0 && cfg.num_refresh_vars < C::NB * C::Z;
     Cfg<T> g;
     g.rule = cfg.rule; g.max_iters = cfg.max_iters; g.early_exit = cfg.early_exit;
-    g.float_syndrome0 = 0; g.num_active_checks = -1; g.num_refresh_vars = -1;
+    g.float_syndrome0 = 0; g.num_active_checks = -1; g.num_refresh_vars = bounded ? cfg.num_refresh_vars : -1;
     g.scale = (T)cfg.scale; g.clip_tanh_arg = (T)0; g.clip_prod = (T)0; g.clip_post = (T)0; g.offset = (T)cfg.offset;
     auto k = spec_r1w_kernel<C, T, TL, F, W, kOms>;
     if constexpr (F > 1) {  // early exit with several slots: every slot runs its own queue of frames
         if (cfg.early_exit && cfg.max_iters >= 1) k = spec_r1w_slots_kernel<C, T, TL, F, W, kOms>;
+    }
+    if (bounded) {
+        if constexpr (r1w_refresh_built<C>()) {
+            k = spec_r1w_kernel<C, T, TL, F, W, kOms, true>;
+            if constexpr (F > 1) {
+                if (cfg.early_exit && cfg.max_iters >= 1) k = spec_r1w_slots_kernel<C, T, TL, F, W, kOms, true>;
+            }
+        } else {
+            *supported = false;
+            return hipSuccess;
+        }
     }
     int per_cu = 0;
     hipError_t e = kernel_setup(reinterpret_cast<const void *>(k), 64 * W * G, LY::LDS_BYTES, &per_cu);
@@ -655,14 +681,14 @@ static hipError_t launch_r1w_code(const ldpc_decode_config &cfg, int compute_dty
     if constexpr (r1w_wanted<C, double, FD>()) {
         constexpr int W = r1w_waves<C, double, FD>();
         if (compute_dtype == LDPC_F64) {
-            if (io.llr_dtype == LDPC_F64) return launch_r1w<C, double, double, FD, W>(cfg, io, num_cus, name);
-            return launch_r1w<C, double, float, FD, W>(cfg, io, num_cus, name);
+            if (io.llr_dtype == LDPC_F64) return launch_r1w<C, double, double, FD, W>(cfg, io, num_cus, name, supported);
+            return launch_r1w<C, double, float, FD, W>(cfg, io, num_cus, name, supported);
         }
     }
     if constexpr (r1w_wanted<C, float, FF>()) {
         constexpr int W = r1w_waves<C, float, FF>();
         if (compute_dtype == LDPC_F32 && io.llr_dtype == LDPC_F32)
-            return launch_r1w<C, float, float, FF, W>(cfg, io, num_cus, name);
+            return launch_r1w<C, float, float, FF, W>(cfg, io, num_cus, name, supported);
     }
     *supported = false;
     return hipSuccess;

@@ -26,7 +26,9 @@ struct SpawLayout {
     static constexpr int LDS_BYTES = FLAG_OFF + 64;
 };
 
-template <int RULE, class C, typename T, typename TL, int F, int W>
+// REF: variables from g.num_refresh_vars on keep sending their channel value (the reference's refresh
+// loops run over range(self.n), the constructor's n: bpsk.py:356, channel.py:358,480).
+template <int RULE, class C, typename T, typename TL, int F, int W, bool REF = false>
 __global__ void __launch_bounds__(64 * W * ((F * C::Z + 63) / 64))
 spec_spaw_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__restrict__ hard_out,
                  int *__restrict__ iters_out, uint8_t *__restrict__ conv_out, T *__restrict__ post_out)
@@ -200,7 +202,9 @@ spec_spaw_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t
                                         qn[k + 1] = sw[k] ? a : b;
                                     }
                                 });
-                                static_for<0, D>([&](auto k) { *reinterpret_cast<T *>(msg_b + off[k]) = qn[k]; });
+                                bool refresh = true;
+                                if constexpr (REF) refresh = bc * Z + z < g.num_refresh_vars;
+                                static_for<0, D>([&](auto k) { *reinterpret_cast<T *>(msg_b + off[k]) = refresh ? qn[k] : L[j]; });
                                 T b = L[j] + run;
                                 if (g.clip_post > (T)0) b = clip(b, -g.clip_post, g.clip_post);
                                 own[j] = b;
@@ -236,7 +240,7 @@ spec_spaw_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t
 // (b + k * gridDim.x) * F + s and starts the next one when the current one ends; the slots share
 // the three barriers of an iteration.  Same arithmetic as spec_spaw_kernel; early exit only,
 // max_iters >= 1.
-template <int RULE, class C, typename T, typename TL, int F, int W>
+template <int RULE, class C, typename T, typename TL, int F, int W, bool REF = false>
 __global__ void __launch_bounds__(64 * W * ((F * C::Z + 63) / 64))
 spec_spaw_slots_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__restrict__ hard_out,
                        int *__restrict__ iters_out, uint8_t *__restrict__ conv_out, T *__restrict__ post_out)
@@ -410,7 +414,9 @@ spec_spaw_slots_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, u
                                     qn[k + 1] = sw[k] ? a : b;
                                 }
                             });
-                            static_for<0, D>([&](auto k) { *reinterpret_cast<T *>(msg_b + off[k]) = qn[k]; });
+                            bool refresh = true;
+                                if constexpr (REF) refresh = bc * Z + z < g.num_refresh_vars;
+                                static_for<0, D>([&](auto k) { *reinterpret_cast<T *>(msg_b + off[k]) = refresh ? qn[k] : L[j]; });
                             T b = L[j] + run;
                             if (g.clip_post > (T)0) b = clip(b, -g.clip_post, g.clip_post);
                             own[j] = b;
@@ -453,19 +459,36 @@ spec_spaw_slots_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, u
 }
 
 // ------------------------------------------------------------------------------------------ host
+// built for the large base graphs (the reference's own call shape: its 5G matrix under a constructor n of 648,
+// channel.py:646,842); elsewhere the table-driven kernels serve the bound
+template <class C>
+constexpr bool spaw_refresh_built() { return C::EB > 100; }
+
 template <int RULE, class C, typename T, typename TL, int F, int W>
-static hipError_t launch_spaw(const ldpc_decode_config &cfg, const Launch &io, int num_cus, const char **name)
+static hipError_t launch_spaw(const ldpc_decode_config &cfg, const Launch &io, int num_cus, const char **name, bool *supported)
 {
     typedef SpawLayout<C, T, F> LY;
     constexpr int G = (LY::LANES + 63) / 64;
+    const bool bounded = cfg.num_refresh_vars >= 0 && cfg.num_refresh_vars < C::NB * C::Z;
     Cfg<T> g;
     g.rule = RULE; g.max_iters = cfg.max_iters; g.early_exit = cfg.early_exit;
-    g.float_syndrome0 = 0; g.num_active_checks = -1; g.num_refresh_vars = -1;
+    g.float_syndrome0 = 0; g.num_active_checks = -1; g.num_refresh_vars = bounded ? cfg.num_refresh_vars : -1;
     g.scale = (T)cfg.scale; g.clip_tanh_arg = (T)cfg.clip_tanh_arg; g.clip_prod = (T)cfg.clip_prod;
     g.clip_post = (T)cfg.clip_post; g.offset = (T)cfg.offset;
     auto k = spec_spaw_kernel<RULE, C, T, TL, F, W>;
     if constexpr (F > 1) {  // early exit with several slots: every slot runs its own queue of frames
         if (cfg.early_exit && cfg.max_iters >= 1) k = spec_spaw_slots_kernel<RULE, C, T, TL, F, W>;
+    }
+    if (bounded) {
+        if constexpr (spaw_refresh_built<C>()) {
+            k = spec_spaw_kernel<RULE, C, T, TL, F, W, true>;
+            if constexpr (F > 1) {
+                if (cfg.early_exit && cfg.max_iters >= 1) k = spec_spaw_slots_kernel<RULE, C, T, TL, F, W, true>;
+            }
+        } else {
+            *supported = false;
+            return hipSuccess;
+        }
     }
     int per_cu = 0;
     hipError_t e = kernel_setup(reinterpret_cast<const void *>(k), 64 * W * G, LY::LDS_BYTES, &per_cu);
@@ -517,14 +540,14 @@ static hipError_t launch_spaw_rule(const ldpc_decode_config &cfg, int compute_dt
     if constexpr (spaw_wanted<C, double, FD>()) {
         constexpr int W = FD * C::Z > 64 ? LDPC_SPAW_WAVES_PACKED : LDPC_SPAW_WAVES;
         if (compute_dtype == LDPC_F64) {
-            if (io.llr_dtype == LDPC_F64) return launch_spaw<RULE, C, double, double, FD, W>(cfg, io, num_cus, name);
-            return launch_spaw<RULE, C, double, float, FD, W>(cfg, io, num_cus, name);
+            if (io.llr_dtype == LDPC_F64) return launch_spaw<RULE, C, double, double, FD, W>(cfg, io, num_cus, name, supported);
+            return launch_spaw<RULE, C, double, float, FD, W>(cfg, io, num_cus, name, supported);
         }
     }
     if constexpr (spaw_wanted<C, float, FF>()) {
         constexpr int W = FF * C::Z > 64 ? LDPC_SPAW_WAVES_PACKED : LDPC_SPAW_WAVES;
         if (compute_dtype == LDPC_F32 && io.llr_dtype == LDPC_F32)
-            return launch_spaw<RULE, C, float, float, FF, W>(cfg, io, num_cus, name);
+            return launch_spaw<RULE, C, float, float, FF, W>(cfg, io, num_cus, name, supported);
     }
     *supported = false;
     return hipSuccess;

@@ -362,7 +362,8 @@ static int decode_impl(ldpc_code *c, const ldpc_decode_config *cfg, const void *
         if (!supported) return fail(LDPC_ERR_UNSUPPORTED, "bit flipping keeps 5 n + m bytes of a frame in LDS: the matrix is too large");
         return LDPC_OK;
     }
-    // the loop-bound quirks exist in the edge-list kernel and in the table-driven circulant kernels
+    // the loop-bound quirks exist in the edge-list kernel, in the table-driven circulant kernels and, as template
+    // switches, in some compiled-in kernels (launch_spec_bounded)
     const bool quirks = (cfg->rule == 0 && cfg->num_active_checks >= 0 && cfg->num_active_checks < c->m) ||
                         (cfg->rule != 0 && cfg->num_refresh_vars >= 0 && cfg->num_refresh_vars < c->n);
     if (kernel == LDPC_KERNEL_QC && !c->has_qc) return fail(LDPC_ERR_ARG, "no QC description attached to this code");
@@ -385,6 +386,12 @@ static int decode_impl(ldpc_code *c, const ldpc_decode_config *cfg, const void *
     if (kernel == LDPC_KERNEL_AUTO && c->has_qc && !quirks && c->spec_id >= 0 && spec_ok && lnms_rows < 0) {
         bool supported = false;
         hipError_t e = launch_spec(c->spec_id, *cfg, compute_dtype, io, c->num_cus, &g_kernel, &supported);
+        if (e != hipSuccess) return fail(LDPC_ERR_HIP, "specialised kernel launch: %s", hipGetErrorString(e));
+        if (supported) return LDPC_OK;
+    }
+    if (kernel == LDPC_KERNEL_AUTO && c->has_qc && quirks && c->spec_id >= 0 && spec_ok && cfg->rule != LDPC_RULE_LNMS) {
+        bool supported = false;  // the loop bounds as template switches of some compiled-in kernels
+        hipError_t e = launch_spec_bounded(c->spec_id, *cfg, compute_dtype, io, c->num_cus, &g_kernel, &supported);
         if (e != hipSuccess) return fail(LDPC_ERR_HIP, "specialised kernel launch: %s", hipGetErrorString(e));
         if (supported) return LDPC_OK;
     }

@@ -71,10 +71,10 @@ def test_ccsds_caller_shape():
 
 def test_loop_bound_quirks_on_gpu(c_oracle):
     """self.m / self.n taken from the constructor instead of the matrix (ldpc.py:30,175; bpsk.py:244):
-    served by the table-driven circulant kernels (automatic choice for a circulant code) and by the
-    edge-list kernel, both identical to the CPU restatement.  The cases include the reference's own
-    callers: 8 active rows on the CCSDS matrix (ccsds.py:18) and n = 648 on the 2080-column 5G matrix
-    (channel.py:646)."""
+    served by the table-driven circulant kernels and by the edge-list kernel everywhere, and by the
+    compiled-in kernels (as template switches) for the reference's own callers: active rows on the CCSDS
+    matrix (ccsds.py:18 gives 8) and n = 648 on the 2080-column 5G matrix (channel.py:646) - all identical
+    to the CPU restatement, early exit and fixed work, double and float."""
     from ldpc_amd.decoder import Decoder
     rng = np.random.default_rng(21)
     cases = [("wifi648", config.R0.with_(num_active_checks=100)),
@@ -83,9 +83,18 @@ def test_loop_bound_quirks_on_gpu(c_oracle):
              ("wifi648", config.OMS.with_(num_refresh_vars=40, max_iters=8)),
              ("ccsds512", config.R0.with_(num_active_checks=8)),
              ("ccsds512", config.R0.with_(num_active_checks=70)),      # boundary inside a block row
+             ("ccsds512", config.R0.with_(num_active_checks=70, early_exit=False, max_iters=6)),
              ("ccsds512", config.R1.with_(num_refresh_vars=100, max_iters=10)),
+             ("nr_bg2_z40_r1400", config.R1.with_(num_refresh_vars=648, max_iters=12)),
+             ("nr_bg2_z40_r1400", config.R1.with_(num_refresh_vars=648, max_iters=5, early_exit=False)),
+             ("nr_bg2_z40", config.R1.with_(num_refresh_vars=1000, max_iters=8)),
+             ("nr_bg2_z40_r1400", config.R2.with_(num_refresh_vars=648, max_iters=6)),
              ("nr_bg2_z40_r1400", config.R3.with_(num_refresh_vars=648, max_iters=10)),
+             ("nr_bg2_z40_r1400", config.R3.with_(num_refresh_vars=648, max_iters=4, early_exit=False)),
              ("nr_bg2_z40_r1400", config.R4.with_(num_refresh_vars=648, max_iters=10))]
+    # which of them run on compiled-in kernels under the automatic choice
+    compiled = {("ccsds512", 0): "spec_r0_", ("wifi648", 0): "spec_r0_", ("nr_bg2_z40_r1400", 1): "spec_r1w_", ("nr_bg2_z40", 1): "spec_r1w_",
+                ("nr_bg2_z40_r1400", 2): "spec_spaw_", ("nr_bg2_z40_r1400", 3): "spec_spaw_", ("nr_bg2_z40_r1400", 4): "spec_spaw_"}
     decs = {}
     for name, cfg in cases:
         code = codes.load_packaged(name)
@@ -93,7 +102,7 @@ def test_loop_bound_quirks_on_gpu(c_oracle):
         L = 4.0 * (-1.0 + 0.9 * rng.standard_normal((48, code.n)))
         L = L if cfg.rule == 0 else -L
         eh, ei, ec, ep = c_oracle.c_decode(code, cfg, L)
-        for kernel, prefix in ((0, "qc"), (1, "csr")):
+        for kernel, prefix in ((0, compiled.get((name, cfg.rule), "qc")), (2, "qc"), (1, "csr")):
             res = dec.decode(L, cfg, want_posterior=True, kernel=kernel)
             assert res.kernel.startswith(prefix), (name, cfg.rule, res.kernel)
             assert np.array_equal(res.iters, ei) and np.array_equal(res.converged, ec), (name, cfg.rule, kernel)
@@ -102,6 +111,10 @@ def test_loop_bound_quirks_on_gpu(c_oracle):
                 assert np.array_equal(res.posterior, ep), (name, cfg.rule, kernel)
             else:
                 np.testing.assert_allclose(res.posterior, ep, rtol=1e-4, atol=1e-7)
+        if (name, cfg.rule) in compiled:   # the float instantiation carries the switch as well
+            res = dec.decode(L.astype(np.float32), cfg, compute_dtype=np.float32)
+            assert res.kernel.startswith(compiled[(name, cfg.rule)]), res.kernel
+            assert (res.iters == ei).mean() > 0.9 and ((res.hard != eh).any(axis=1) & (res.converged & ec)).mean() < 0.05
 
 
 def test_irregular_matrix_without_circulant_structure(c_oracle):
