@@ -377,7 +377,11 @@ def bg1_workloads(torch, dist, device, world, rank, args):
     frames = 16384
     out = {"workload": f"nr_bg1_z384 (n={bg1.code.n}, k={bg1.k}; BG1 connectivity, synthetic shifts) x {frames} "
                        f"frames/launch/GPU, rule LNMS (row-layered normalised min-sum, build extension), exactly 10 sweeps",
-           "metric": "decoded info Gbit/s"}
+           "metric": "decoded info Gbit/s",
+           "headline_dtype": "f32",
+           "headline_dtype_reason": "layered min-sum is a build extension: no reference arithmetic to reproduce; float32 and "
+                                    "float64 decode 131072 waterfall frames to the same words, 1 frame differing in flag and sweep "
+                                    "count (tests/test_gpu_precision.py); double holds one frame per compute unit instead of two"}
     for dtype in ("f32", "f64"):
         r, batch, cfg = bg1.run("LNMS", dtype, 0.0, False, frames, 5, 1, seed=9, with_rooflines=True)
         r.pop("counters")
@@ -385,6 +389,12 @@ def bg1_workloads(torch, dist, device, world, rank, args):
             r["cpu_baseline"] = cpu_baseline(bg1.code, cfg, batch, bg1.k, dtype, 5.0)
         out[dtype] = r
         del batch
+    # the same rule on the kernel that takes lifting size, shift table and active block rows at run time (what any
+    # other 38.212 table, lifting size or rate-matched sub-matrix runs on; bit-identical results)
+    r, batch, cfg = bg1.run("LNMS", "f32", 0.0, False, frames, 5, 1, seed=9, kernel=3, with_rooflines=True)
+    r.pop("counters")
+    out["f32_run_time_shifts"] = r
+    del batch
     # reduced-precision fast mode: packed half precision, two frames per lane (validated statistically only)
     r, batch, cfg = bg1.run("LNMS", "f16", 0.0, False, frames, 5, 1, seed=9, with_rooflines=True)
     r.pop("counters")

@@ -43,3 +43,44 @@ def test_float32_and_device_transcendental_disagreement_rates():
             v = r["f64_vs_numpy"]
             assert v["iters_diff"] == 0 and v["conv_diff"] == 0 and v["hard_diff"] == 0, (key, v)
             assert v["max_rel_posterior"] <= (1e-3 if rule == "R4" else 1e-4), (key, v)
+
+
+def test_bg1_layered_float_against_double_on_131072_frames():
+    """The BG1 Z = 384 half of the metric is quoted in float32 (the layered rule has no reference
+    counterpart whose float64 it would have to reproduce; in double the kernel holds one frame per
+    compute unit instead of two).  What that costs in results, on 2^17 frames at the waterfall
+    (Es/N0 -3.75 dB): the two arithmetic types never decode a frame to two different words, and at most
+    a handful of frames change their convergence flag or sweep count."""
+    import numpy as np
+    import torch
+
+    import precision_rates
+    from ldpc_amd import codes, config, sweep
+    from ldpc_amd.decoder import Decoder
+    dev = torch.device("cuda", 0)
+    code = codes.load_packaged("nr_bg1_z384")
+    G = codes.load_packaged_generator("nr_bg1_z384")
+    dec = Decoder(code)
+    cfg = config.LNMS
+    frames, step = 1 << 17, 8192
+    tot = dict(conv_diff=0, iters_diff=0, hard_diff=0, conv64=0, wrong=0)
+    for c in range(0, frames, step):
+        batch = sweep.make_batch(code, G, step, -3.75, cfg, seed=[47, c], device=dev, native_noise=True, first_frame=c)
+        res = {}
+        for dt in (np.float64, np.float32):
+            kern = sweep.decode_batch(dec, batch, cfg, compute_dtype=dt)
+            torch.cuda.synchronize()
+            res[dt] = (batch.hard.clone(), batch.iters.clone(), batch.converged.clone())
+        assert kern == "spec_lnms_f32"
+        (h64, i64, c64), (h32, i32, c32) = res[np.float64], res[np.float32]
+        tot["conv_diff"] += int((c64 != c32).sum())
+        tot["iters_diff"] += int((i64 != i32).sum())
+        tot["hard_diff"] += int(((h64 != h32).any(dim=1) & (c64 != 0) & (c32 != 0)).sum())
+        tot["conv64"] += int(c64.sum())
+        tot["wrong"] += int(((h64 != batch.ref).any(dim=1) & (c64 != 0)).sum())
+        del batch
+    fer = 1 - tot["conv64"] / frames
+    print("BG1 float32 against float64,", frames, "frames:", tot, "FER", fer)
+    assert 0.005 < fer < 0.3, fer
+    assert tot["hard_diff"] == 0 and tot["wrong"] == 0
+    assert tot["conv_diff"] <= 3 and tot["iters_diff"] <= 16, tot
