@@ -504,6 +504,30 @@ def link_workloads(head, bg2, args, torch, dist, device, world, rank):
                                              "codes": [head.name, bg2.name], "rule": "R3", "dtype": "f32",
                                              "cfo_cycles_per_symbol": cfo, "es_n0_db": [1.0, -4.0], "fer": st["fer"],
                                              "mean_iters": st["mean_iters"], "early_exit": True}
+    # rooflines of the step (two decode kernels side by side on two streams, then the error accounting):
+    # HBM from the algorithmic bytes of decode (5 n + 5 per frame) and accounting (2 n + 5 per frame) over the
+    # step time; vector issue from the instruction counts on file for the two sum-product kernels
+    # (they are bound by their transcendentals: tanh and atanh per edge and iteration)
+    step_s = w / 3
+    mixed_bytes = sum(fr * (7 * r.code.n + 10) for r, fr in ((head, 1 << 16), (bg2, 1 << 13)))
+    roof = {"bound": "hbm", "achieved": mixed_bytes / step_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
+            "bytes_per_step": mixed_bytes, "step_ms": step_s * 1e3}
+    roof["frac"] = roof["achieved"] / roof["peak"]
+    res["mixed_ccsds_bg2_R3_f32_doppler"]["roofline"] = roof
+    valu = 0.0
+    have = True
+    for (runner, fr), key, kname in (((head, 1 << 16), "ccsds512/R3/f32/f32llr", "spec_spa_f32"), ((bg2, 1 << 13), "nr_bg2_z40/R3/f32/f32llr", "spec_spaw_f32")):
+        sq = _profile_record("sq_counters", key, True, kname)   # counted in fixed-work mode: per executed frame-iteration
+        have = have and sq is not None
+        if sq:
+            valu += sq["valu_wave_instructions_per_frame_iteration"] * fr
+    if have:   # iterations executed: mean over both codes' frames (failures run one more than they report)
+        executed_per_frame = st["mean_iters"] + st["fer"]
+        ach = valu * executed_per_frame / step_s / 1e9
+        res["mixed_ccsds_bg2_R3_f32_doppler"]["valu_roofline"] = {
+            "bound": "valu", "achieved": ach, "peak": VALU_PEAK_GIPS, "unit": "G wave-instructions/s", "frac": ach / VALU_PEAK_GIPS,
+            "note": "instruction counts per frame-iteration from the fixed-work counter passes of the two kernels, "
+                    "iterations from this run's counters (mean over both codes)"}
     del parts
     # encoder and rate recovery of the 5G-structured table at Z = 384 (HBM-bound byte work)
     from ldpc_amd import codes

@@ -17,6 +17,7 @@
 // syndrome test at the top of the iteration, bpsk.py:205-209) | barrier | slots whose syndrome is
 // zero stop here, before their update | variable phase | barrier.
 #include "spec_r1w_plan.h"
+#include "sweep_fused.h"
 
 namespace ldpc {
 
@@ -28,16 +29,22 @@ struct R1wLayout {
     static constexpr int HB_BYTES = ((C::NB * C::Z + 15) / 16) * 16;
     static constexpr int SLOT_BYTES = ((QV_BYTES + CS_BYTES + HB_BYTES + 127) / 128) * 128 + (F > 1 ? 32 : 0);
     static constexpr int FLAG_OFF = F * SLOT_BYTES;
-    static constexpr int LDS_BYTES = FLAG_OFF + 64;
+    static constexpr int LDS_BYTES = FLAG_OFF + 96;  // flags: two rows of eight (syndromes), one more for the fused sweep
 };
 
 // REF: the refresh loop of the reference runs over range(self.n), the CONSTRUCTOR's n (bpsk.py:244,
 // channel.py:241): variables from g.num_refresh_vars on keep sending their channel value.  A switch of
 // its own so that the plain kernel does not pay the comparison and the selects.
-template <class C, typename T, typename TL, int F, int W, bool OMS, bool REF = false>  // OMS: the offset rule (LDPC_RULE_OMS) instead of R1's
+// FUSED: channel in front and error accounting behind inside the kernel (sweep_fused.h).  The workgroup
+// draws the LLRs of its F frames into its own slice of `scratch` ([F][n] floats in device memory,
+// reused group after group, hence cache-resident: beside three frames' messages LDS has no room for
+// them) and decodes from there; every lane counts the bit errors of the variables it owns against the
+// transmitted word, the per-frame flags meet in LDS.  llr and the result arrays are unused.
+template <class C, typename T, typename TL, int F, int W, bool OMS, bool REF = false, bool FUSED = false>  // OMS: the offset rule (LDPC_RULE_OMS) instead of R1's
 __global__ void __launch_bounds__(64 * W * ((F * C::Z + 63) / 64))
 spec_r1w_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__restrict__ hard_out,
-                int *__restrict__ iters_out, uint8_t *__restrict__ conv_out, T *__restrict__ post_out)
+                int *__restrict__ iters_out, uint8_t *__restrict__ conv_out, T *__restrict__ post_out, SweepDev sp,
+                float *scratch)
 {
     typedef R1wLayout<C, T, F> LY;
     typedef R1wPlan<C, W> PL;
@@ -57,11 +64,16 @@ spec_r1w_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t 
     unsigned char *hb_b = cs_b + LY::CS_BYTES;                // [NB][Z] u8
     int *flags = reinterpret_cast<int *>(smem + LY::FLAG_OFF);  // [2][8]: failed-syndrome flag per slot, double-buffered by iteration parity
     const unsigned zb = (unsigned)z * ST, zp = (unsigned)z * SP, z1 = (unsigned)z;
+    SweepAcc acc;
 
     const long long groups = (frames + F - 1) / F;
     for (long long grp = blockIdx.x; grp < groups; grp += gridDim.x) {
         const long long frame = grp * F + f;
         const bool active = lane_on && frame < frames;
+        const float *mine = nullptr;
+        if constexpr (FUSED) {
+            mine = sweep_stage_group<n, F>(sp, scratch, grp, frames);
+        }
         T L[NBW], own[NBW], q[QW];
         // ---- start: every edge carries the channel LLR (bpsk.py:170-177)
         static_for<0, W>([&](auto w) {
@@ -70,7 +82,9 @@ spec_r1w_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t 
                     if constexpr (j < PL::COLS.cnt[w]) {
                         constexpr int bc = PL::COLS.item[w][j];
                         constexpr int k0 = C::col_ptr[bc], D = C::col_ptr[bc + 1] - k0, q0 = PL::COLS.edge0[w][j];
-                        const T l = (active ? (T)llr[frame * n + bc * Z + z] : (T)0) + (T)0;  // -0.0 -> +0.0: signs are sign bits from here on
+                        T l;
+                        if constexpr (FUSED) l = (active ? (T)mine[f * n + bc * Z + z] : (T)0) + (T)0;
+                        else l = (active ? (T)llr[frame * n + bc * Z + z] : (T)0) + (T)0;  // -0.0 -> +0.0: signs are sign bits from here on
                         L[j] = l;
                         own[j] = l;
                         if (lane_on) hb_b[bc * Z + z1] = (uint8_t)hard_bit<1>(l);  // idle lanes alias lane 0
@@ -82,7 +96,7 @@ spec_r1w_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t 
                 });
             }
         });
-        if (threadIdx.x < 16) flags[threadIdx.x] = 0;
+        if (threadIdx.x < 24) flags[threadIdx.x] = 0;
         __syncthreads();
 
         bool done = !active;
@@ -196,8 +210,26 @@ spec_r1w_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t 
             }
             __syncthreads();
         }
-        // ---- results: every wave writes its own columns
-        if (active) {
+        // ---- results: every wave writes its own columns (fused: counts their bit errors)
+        if constexpr (FUSED) {
+            unsigned errs = 0;
+            if (active) {
+                const uint8_t *rf = sp.ref ? sp.ref + frame * sp.ref_stride : nullptr;
+                static_for<0, W>([&](auto w) {
+                    if (wave == w) {
+                        static_for<0, NBW>([&](auto j) {
+                            if constexpr (j < PL::COLS.cnt[w]) {
+                                constexpr int bc = PL::COLS.item[w][j];
+                                errs += hard_bit<1>(own[j]) != (rf ? (unsigned)rf[bc * Z + z] : 0u);
+                            }
+                        });
+                    }
+                });
+            }
+            if (errs) flags[16 + f] = 1;
+            __syncthreads();
+            if (active) acc.book(errs, flags[16 + f] != 0, wave == 0 && z == 0, res_iters, res_conv);
+        } else if (active) {
             static_for<0, W>([&](auto w) {
                 if (wave == w) {
                     static_for<0, NBW>([&](auto j) {
@@ -213,6 +245,7 @@ spec_r1w_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t 
         }
         __syncthreads();
     }
+    if constexpr (FUSED) acc.flush_wave(sp.counters);
 }
 
 // ------------------------------------------------------------------------------ R1, independent slots
@@ -227,7 +260,7 @@ spec_r1w_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t 
 template <class C, typename T, typename TL, int F, int W, bool OMS, bool REF = false>  // OMS, REF: as above
 __global__ void __launch_bounds__(64 * W * ((F * C::Z + 63) / 64))
 spec_r1w_slots_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__restrict__ hard_out,
-                      int *__restrict__ iters_out, uint8_t *__restrict__ conv_out, T *__restrict__ post_out)
+                      int *__restrict__ iters_out, uint8_t *__restrict__ conv_out, T *__restrict__ post_out, SweepDev, float *)
 {
     typedef R1wLayout<C, T, F> LY;
     typedef R1wPlan<C, W> PL;
@@ -431,13 +464,14 @@ struct R0wLayout {
     static constexpr int CS_BYTES = C::MB * C::Z * 2 * (int)sizeof(T);
     static constexpr int SLOT_BYTES = ((POST_BYTES + CS_BYTES + 127) / 128) * 128 + (F > 1 ? 32 : 0);
     static constexpr int FLAG_OFF = F * SLOT_BYTES;
-    static constexpr int LDS_BYTES = FLAG_OFF + 64;
+    static constexpr int LDS_BYTES = FLAG_OFF + 96;  // flags: two rows of eight (syndromes), one more for the fused sweep
 };
 
-template <class C, typename T, typename TL, int F, int W>
+template <class C, typename T, typename TL, int F, int W, bool FUSED = false>  // FUSED: as in spec_r1w_kernel
 __global__ void __launch_bounds__(64 * W * ((F * C::Z + 63) / 64))
 spec_r0w_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__restrict__ hard_out,
-                int *__restrict__ iters_out, uint8_t *__restrict__ conv_out, T *__restrict__ post_out)
+                int *__restrict__ iters_out, uint8_t *__restrict__ conv_out, T *__restrict__ post_out, SweepDev sp,
+                float *scratch)
 {
     typedef R0wLayout<C, T, F> LY;
     typedef R1wPlan<C, W> PL;
@@ -456,11 +490,16 @@ spec_r0w_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t 
     unsigned char *cs_b = post_b + LY::POST_BYTES;      // [MB][Z] Pair
     int *flags = reinterpret_cast<int *>(smem + LY::FLAG_OFF);  // [2][8], as in the R1 kernel
     const unsigned zb = (unsigned)z * ST, zp = (unsigned)z * SP;
+    SweepAcc acc;
 
     const long long groups = (frames + F - 1) / F;
     for (long long grp = blockIdx.x; grp < groups; grp += gridDim.x) {
         const long long frame = grp * F + f;
         const bool active = lane_on && frame < frames;
+        const float *mine = nullptr;
+        if constexpr (FUSED) {
+            mine = sweep_stage_group<n, F>(sp, scratch, grp, frames);
+        }
         T L[NBW], own[NBW];
         static_for<0, W>([&](auto w) {
             if (wave == w) {
@@ -468,7 +507,9 @@ spec_r0w_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t 
                     if constexpr (j < PL::COLS.cnt[w]) {
                         constexpr int bc = PL::COLS.item[w][j];
                         // + 0.0 turns -0.0 into +0.0: from here on "negative" is exactly "sign bit set"
-                        const T l = (active ? (T)llr[frame * n + bc * Z + z] : (T)0) + (T)0;
+                        T l;
+                        if constexpr (FUSED) l = (active ? (T)mine[f * n + bc * Z + z] : (T)0) + (T)0;
+                        else l = (active ? (T)llr[frame * n + bc * Z + z] : (T)0) + (T)0;
                         L[j] = l;
                         own[j] = l;  // ldpc.py:154
                         if (lane_on) *reinterpret_cast<T *>(post_b + bc * Z * ST + zb) = l;  // idle lanes alias lane 0
@@ -476,7 +517,7 @@ spec_r0w_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t 
                 });
             }
         });
-        if (threadIdx.x < 16) flags[threadIdx.x] = 0;
+        if (threadIdx.x < 24) flags[threadIdx.x] = 0;
         __syncthreads();
 
         bool done = !active, float_hard = false;
@@ -572,7 +613,27 @@ spec_r0w_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t 
             }
             __syncthreads();
         }
-        if (active) {
+        if constexpr (FUSED) {
+            unsigned errs = 0;
+            if (active) {
+                const uint8_t *rf = sp.ref ? sp.ref + frame * sp.ref_stride : nullptr;
+                static_for<0, W>([&](auto w) {
+                    if (wave == w) {
+                        static_for<0, NBW>([&](auto j) {
+                            if constexpr (j < PL::COLS.cnt[w]) {
+                                constexpr int bc = PL::COLS.item[w][j];
+                                const T v = own[j];
+                                const unsigned hv = float_hard ? (v == (T)0 ? 0u : (v == (T)1 ? 1u : 2u)) : hard_bit<0>(v);
+                                errs += hv != (rf ? (unsigned)rf[bc * Z + z] : 0u);
+                            }
+                        });
+                    }
+                });
+            }
+            if (errs) flags[16 + f] = 1;
+            __syncthreads();
+            if (active) acc.book(errs, flags[16 + f] != 0, wave == 0 && z == 0, res_iters, res_conv);
+        } else if (active) {
             static_for<0, W>([&](auto w) {
                 if (wave == w) {
                     static_for<0, NBW>([&](auto j) {
@@ -590,6 +651,7 @@ spec_r0w_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t 
         }
         __syncthreads();
     }
+    if constexpr (FUSED) acc.flush_wave(sp.counters);
 }
 
 // Frame slots per workgroup: the code's slot count when those frames fit one wave; when they need
@@ -618,7 +680,8 @@ template <class C>
 constexpr bool r1w_refresh_built() { return !kOms && C::EB > 100; }
 
 template <class C, typename T, typename TL, int F, int W>
-static hipError_t launch_r1w(const ldpc_decode_config &cfg, const Launch &io, int num_cus, const char **name, bool *supported)
+static hipError_t launch_r1w(const ldpc_decode_config &cfg, const Launch &io, int num_cus, const char **name, bool *supported,
+                             const SweepDev *sp = nullptr, Scratch *ws = nullptr)
 {
     typedef R1wLayout<C, T, F> LY;
     constexpr int G = (LY::LANES + 63) / 64;
@@ -627,6 +690,28 @@ static hipError_t launch_r1w(const ldpc_decode_config &cfg, const Launch &io, in
     g.rule = cfg.rule; g.max_iters = cfg.max_iters; g.early_exit = cfg.early_exit;
     g.float_syndrome0 = 0; g.num_active_checks = -1; g.num_refresh_vars = bounded ? cfg.num_refresh_vars : -1;
     g.scale = (T)cfg.scale; g.clip_tanh_arg = (T)0; g.clip_prod = (T)0; g.clip_post = (T)0; g.offset = (T)cfg.offset;
+    if (sp) {  // fused sweep: float LLRs drawn in the kernel, no loop bound; the slots start and end together
+        if constexpr (sizeof(TL) == 4 && (C::NB * C::Z) % 4 == 0) {
+            if (bounded) { *supported = false; return hipSuccess; }
+            auto kf = spec_r1w_kernel<C, T, TL, F, W, kOms, false, true>;
+            int per_cu = 0;
+            hipError_t e = kernel_setup(reinterpret_cast<const void *>(kf), 64 * W * G, LY::LDS_BYTES, &per_cu);
+            if (e != hipSuccess) return e;
+            if (per_cu < 1) per_cu = 1;
+            const long long groups = (io.frames + F - 1) / F, full = (long long)num_cus * per_cu * 2;
+            long long grid = full > groups ? groups : full;
+            if (grid < 1) grid = 1;
+            e = scratch_reserve(*ws, (size_t)F * C::NB * C::Z * sizeof(float), full, grid);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(64 * W * G), LY::LDS_BYTES, io.stream, g, nullptr, io.frames, nullptr,
+                               nullptr, nullptr, nullptr, *sp, reinterpret_cast<float *>(ws->ptr));
+            *name = kOms ? (sizeof(T) == 8 ? "fused_spec_omsw_f64" : "fused_spec_omsw_f32") : (sizeof(T) == 8 ? "fused_spec_r1w_f64" : "fused_spec_r1w_f32");
+            return hipGetLastError();
+        } else {
+            *supported = false;
+            return hipSuccess;
+        }
+    }
     auto k = spec_r1w_kernel<C, T, TL, F, W, kOms>;
     if constexpr (F > 1) {  // early exit with several slots: every slot runs its own queue of frames
         if (cfg.early_exit && cfg.max_iters >= 1) k = spec_r1w_slots_kernel<C, T, TL, F, W, kOms>;
@@ -652,7 +737,7 @@ static hipError_t launch_r1w(const ldpc_decode_config &cfg, const Launch &io, in
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(64 * W * G), LY::LDS_BYTES, io.stream, g,
                        reinterpret_cast<const TL *>(io.llr), io.frames, io.hard, io.iters, io.converged,
-                       reinterpret_cast<T *>(io.posterior));
+                       reinterpret_cast<T *>(io.posterior), SweepDev{}, nullptr);
     *name = kOms ? (sizeof(T) == 8 ? "spec_omsw_f64" : "spec_omsw_f32") : (sizeof(T) == 8 ? "spec_r1w_f64" : "spec_r1w_f32");
     return hipGetLastError();
 }
@@ -674,28 +759,29 @@ constexpr int r1w_waves() { return R1wLayout<C, T, F>::LDS_BYTES > 80 * 1024 ? 8
 
 template <class C, int SLOTS>
 static hipError_t launch_r1w_code(const ldpc_decode_config &cfg, int compute_dtype, const Launch &io, int num_cus,
-                                  const char **name, bool *supported)
+                                  const char **name, bool *supported, const SweepDev *sp = nullptr, Scratch *ws = nullptr)
 {
     *supported = true;
     constexpr int FD = packed_slots<C, double, SLOTS, R1wLayout>(), FF = packed_slots<C, float, SLOTS, R1wLayout>();
     if constexpr (r1w_wanted<C, double, FD>()) {
         constexpr int W = r1w_waves<C, double, FD>();
         if (compute_dtype == LDPC_F64) {
-            if (io.llr_dtype == LDPC_F64) return launch_r1w<C, double, double, FD, W>(cfg, io, num_cus, name, supported);
-            return launch_r1w<C, double, float, FD, W>(cfg, io, num_cus, name, supported);
+            if (!sp && io.llr_dtype == LDPC_F64) return launch_r1w<C, double, double, FD, W>(cfg, io, num_cus, name, supported);
+            return launch_r1w<C, double, float, FD, W>(cfg, io, num_cus, name, supported, sp, ws);
         }
     }
     if constexpr (r1w_wanted<C, float, FF>()) {
         constexpr int W = r1w_waves<C, float, FF>();
-        if (compute_dtype == LDPC_F32 && io.llr_dtype == LDPC_F32)
-            return launch_r1w<C, float, float, FF, W>(cfg, io, num_cus, name, supported);
+        if (compute_dtype == LDPC_F32 && (sp || io.llr_dtype == LDPC_F32))
+            return launch_r1w<C, float, float, FF, W>(cfg, io, num_cus, name, supported, sp, ws);
     }
     *supported = false;
     return hipSuccess;
 }
 
 template <class C, typename T, typename TL, int F, int W>
-static hipError_t launch_r0w(const ldpc_decode_config &cfg, const Launch &io, int num_cus, const char **name)
+static hipError_t launch_r0w(const ldpc_decode_config &cfg, const Launch &io, int num_cus, const char **name, bool *supported,
+                             const SweepDev *sp = nullptr, Scratch *ws = nullptr)
 {
     typedef R0wLayout<C, T, F> LY;
     constexpr int G = (LY::LANES + 63) / 64;
@@ -703,6 +789,27 @@ static hipError_t launch_r0w(const ldpc_decode_config &cfg, const Launch &io, in
     g.rule = 0; g.max_iters = cfg.max_iters; g.early_exit = cfg.early_exit;
     g.float_syndrome0 = cfg.float_syndrome0; g.num_active_checks = -1; g.num_refresh_vars = -1;
     g.scale = (T)cfg.scale; g.clip_tanh_arg = (T)0; g.clip_prod = (T)0; g.clip_post = (T)0; g.offset = (T)0;
+    if (sp) {  // fused sweep
+        if constexpr (sizeof(TL) == 4 && (C::NB * C::Z) % 4 == 0) {
+            auto kf = spec_r0w_kernel<C, T, TL, F, W, true>;
+            int per_cu = 0;
+            hipError_t e = kernel_setup(reinterpret_cast<const void *>(kf), 64 * W * G, LY::LDS_BYTES, &per_cu);
+            if (e != hipSuccess) return e;
+            if (per_cu < 1) per_cu = 1;
+            const long long groups = (io.frames + F - 1) / F, full = (long long)num_cus * per_cu * 2;
+            long long grid = full > groups ? groups : full;
+            if (grid < 1) grid = 1;
+            e = scratch_reserve(*ws, (size_t)F * C::NB * C::Z * sizeof(float), full, grid);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(64 * W * G), LY::LDS_BYTES, io.stream, g, nullptr, io.frames, nullptr,
+                               nullptr, nullptr, nullptr, *sp, reinterpret_cast<float *>(ws->ptr));
+            *name = sizeof(T) == 8 ? "fused_spec_r0w_f64" : "fused_spec_r0w_f32";
+            return hipGetLastError();
+        } else {
+            *supported = false;
+            return hipSuccess;
+        }
+    }
     auto k = spec_r0w_kernel<C, T, TL, F, W>;
     int per_cu = 0;
     hipError_t e = kernel_setup(reinterpret_cast<const void *>(k), 64 * W * G, LY::LDS_BYTES, &per_cu);
@@ -714,7 +821,7 @@ static hipError_t launch_r0w(const ldpc_decode_config &cfg, const Launch &io, in
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(64 * W * G), LY::LDS_BYTES, io.stream, g,
                        reinterpret_cast<const TL *>(io.llr), io.frames, io.hard, io.iters, io.converged,
-                       reinterpret_cast<T *>(io.posterior));
+                       reinterpret_cast<T *>(io.posterior), SweepDev{}, nullptr);
     *name = sizeof(T) == 8 ? "spec_r0w_f64" : "spec_r0w_f32";
     return hipGetLastError();
 }
@@ -731,20 +838,20 @@ constexpr bool r0w_wanted()
 
 template <class C, int SLOTS>
 static hipError_t launch_r0w_code(const ldpc_decode_config &cfg, int compute_dtype, const Launch &io, int num_cus,
-                                  const char **name, bool *supported)
+                                  const char **name, bool *supported, const SweepDev *sp = nullptr, Scratch *ws = nullptr)
 {
     *supported = true;
     constexpr int W = 4;
     constexpr int FD = packed_slots<C, double, SLOTS, R0wLayout>(), FF = packed_slots<C, float, SLOTS, R0wLayout>();
     if constexpr (r0w_wanted<C, double, FD>()) {
         if (compute_dtype == LDPC_F64) {
-            if (io.llr_dtype == LDPC_F64) return launch_r0w<C, double, double, FD, W>(cfg, io, num_cus, name);
-            return launch_r0w<C, double, float, FD, W>(cfg, io, num_cus, name);
+            if (!sp && io.llr_dtype == LDPC_F64) return launch_r0w<C, double, double, FD, W>(cfg, io, num_cus, name, supported);
+            return launch_r0w<C, double, float, FD, W>(cfg, io, num_cus, name, supported, sp, ws);
         }
     }
     if constexpr (r0w_wanted<C, float, FF>()) {
-        if (compute_dtype == LDPC_F32 && io.llr_dtype == LDPC_F32)
-            return launch_r0w<C, float, float, FF, W>(cfg, io, num_cus, name);
+        if (compute_dtype == LDPC_F32 && (sp || io.llr_dtype == LDPC_F32))
+            return launch_r0w<C, float, float, FF, W>(cfg, io, num_cus, name, supported, sp, ws);
     }
     *supported = false;
     return hipSuccess;
@@ -771,6 +878,34 @@ hipError_t launch_spec_r1w(int spec_id, const ldpc_decode_config &cfg, int compu
 #else
 #define LDPC_LAUNCH(CODE, SLOTS)                                                                   \
     if (spec_id == id) return launch_r1w_code<CODE, SLOTS>(cfg, compute_dtype, io, num_cus, name, supported); \
+    ++id;
+#endif
+    LDPC_FOR_EACH_SPEC_CODE(LDPC_LAUNCH)
+#undef LDPC_LAUNCH
+    *supported = false;
+    return hipSuccess;
+}
+
+// the same kernels as one launch of channel + decode + error accounting (ldpc_sweep_batch)
+#if LDPC_R1W_RULE == 0
+hipError_t launch_spec_r0w_fused(int spec_id, const ldpc_decode_config &cfg, int compute_dtype, const Launch &io, const SweepDev &sp,
+                                 int num_cus, Scratch &workspace, const char **name, bool *supported)
+#elif LDPC_R1W_RULE == 6
+hipError_t launch_spec_omsw_fused(int spec_id, const ldpc_decode_config &cfg, int compute_dtype, const Launch &io, const SweepDev &sp,
+                                  int num_cus, Scratch &workspace, const char **name, bool *supported)
+#else
+hipError_t launch_spec_r1w_fused(int spec_id, const ldpc_decode_config &cfg, int compute_dtype, const Launch &io, const SweepDev &sp,
+                                 int num_cus, Scratch &workspace, const char **name, bool *supported)
+#endif
+{
+    int id = 0;
+#if LDPC_R1W_RULE == 0
+#define LDPC_LAUNCH(CODE, SLOTS)                                                                   \
+    if (spec_id == id) return launch_r0w_code<CODE, SLOTS>(cfg, compute_dtype, io, num_cus, name, supported, &sp, &workspace); \
+    ++id;
+#else
+#define LDPC_LAUNCH(CODE, SLOTS)                                                                   \
+    if (spec_id == id) return launch_r1w_code<CODE, SLOTS>(cfg, compute_dtype, io, num_cus, name, supported, &sp, &workspace); \
     ++id;
 #endif
     LDPC_FOR_EACH_SPEC_CODE(LDPC_LAUNCH)

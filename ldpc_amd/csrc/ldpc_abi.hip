@@ -832,6 +832,11 @@ extern "C" int32_t ldpc_sweep_batch(ldpc_code *c, const ldpc_decode_config *cfg,
                        ? launch_spec_half_fused(c->spec_id, *cfg, io, sp, c->num_cus, &g_kernel, &supported)
                        : launch_spec_fused(c->spec_id, *cfg, compute_dtype, io, sp, c->num_cus, c->workspace_for(io.stream),
                                            &g_kernel, &supported);
+    if (e == hipSuccess && !supported && compute_dtype != LDPC_F16) {  // the multi-wave flooding kernels
+        if (cfg->rule == 0) e = launch_spec_r0w_fused(c->spec_id, *cfg, compute_dtype, io, sp, c->num_cus, c->workspace_for(io.stream), &g_kernel, &supported);
+        else if (cfg->rule == 1) e = launch_spec_r1w_fused(c->spec_id, *cfg, compute_dtype, io, sp, c->num_cus, c->workspace_for(io.stream), &g_kernel, &supported);
+        else if (cfg->rule == LDPC_RULE_OMS) e = launch_spec_omsw_fused(c->spec_id, *cfg, compute_dtype, io, sp, c->num_cus, c->workspace_for(io.stream), &g_kernel, &supported);
+    }
     if (e != hipSuccess) return fail(LDPC_ERR_HIP, "fused sweep launch: %s", hipGetErrorString(e));
     if (!supported)
         return fail(LDPC_ERR_UNSUPPORTED, "no fused sweep kernel for this code, rule and arithmetic; "

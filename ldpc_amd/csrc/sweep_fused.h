@@ -140,6 +140,32 @@ __device__ __forceinline__ void sweep_stage_wave(const SweepDev &sp, float *stag
     }
 }
 
+// Multi-wave workgroups: the channel LLRs of the F frames of group `grp` into the workgroup's own slice
+// of a scratch buffer in device memory ([F][N] floats; reused group after group, i.e. cache-resident),
+// drawn by all threads of the workgroup, four positions per draw.  Ends with the fences and the barrier
+// that make the slice readable by every wave; the caller's previous group must have ended with a barrier.
+template <int N, int F>
+__device__ __forceinline__ const float *sweep_stage_group(const SweepDev &sp, float *scratch, long long grp, long long frames)
+{
+    static_assert(N % 4 == 0, "positions are generated four at a time");
+    constexpr int QUADS = N / 4;
+    float *mine = scratch + (size_t)blockIdx.x * (F * N);
+    for (int i = threadIdx.x; i < F * QUADS; i += blockDim.x) {
+        const int f = F == 1 ? 0 : i / QUADS, qd = i - f * QUADS;
+        long long frame = grp * F + f;
+        if (frame >= frames) frame = frames - 1;  // idle slot: any frame that exists
+        unsigned bits = 0;
+        if (sp.ref) bits = *reinterpret_cast<const unsigned *>(sp.ref + frame * sp.ref_stride + qd * 4) & 0x01010101u;
+        float v[4];
+        channel_quad(sp.ch, sp.ch.first_frame + (unsigned long long)frame, qd, bits, v);
+        *reinterpret_cast<float4 *>(mine + f * N + qd * 4) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    return mine;
+}
+
 // host side: channel parameters of a launch (shared by ldpc_channel_llr and the fused entry point)
 inline ChannelDev make_channel_dev(double sigma2, double gain, int plus_is_bit, int prefix_len, double prefix_llr,
                                    unsigned long long seed, unsigned long long first_frame, double cfo, double phase0)
@@ -168,6 +194,13 @@ hipError_t launch_spec_fused(int spec_id, const ldpc_decode_config &cfg, int com
 // decode_spec_h.hip: rule R1 in packed half precision
 hipError_t launch_spec_half_fused(int spec_id, const ldpc_decode_config &cfg, const Launch &io, const SweepDev &sp,
                                   int num_cus, const char **kernel_name, bool *supported);
+// decode_spec_r1w.hip: the multi-wave flooding kernels (rules R0, R1, OMS on the larger compiled-in codes)
+hipError_t launch_spec_r0w_fused(int spec_id, const ldpc_decode_config &cfg, int compute_dtype, const Launch &io, const SweepDev &sp,
+                                 int num_cus, Scratch &workspace, const char **kernel_name, bool *supported);
+hipError_t launch_spec_r1w_fused(int spec_id, const ldpc_decode_config &cfg, int compute_dtype, const Launch &io, const SweepDev &sp,
+                                 int num_cus, Scratch &workspace, const char **kernel_name, bool *supported);
+hipError_t launch_spec_omsw_fused(int spec_id, const ldpc_decode_config &cfg, int compute_dtype, const Launch &io, const SweepDev &sp,
+                                  int num_cus, Scratch &workspace, const char **kernel_name, bool *supported);
 hipError_t launch_spec_lnms_fused(int spec_id, const ldpc_decode_config &cfg, int compute_dtype, const Launch &io,
                                   const SweepDev &sp, int num_cus, Scratch &workspace, const char **kernel_name,
                                   bool *supported);

@@ -12,7 +12,10 @@ pytestmark = pytest.mark.gpu
 #: (code, rule, Es/N0 dB, frames): operating points where some frames fail and some converge
 CASES = [("ccsds512", "R0", 0.5, 40_000), ("ccsds512", "R1", -0.75, 40_000), ("ccsds512", "OMS", -0.75, 20_000),
          ("wifi648", "R0", 6.0, 20_001), ("wifi648", "R1", -1.0, 20_001), ("nr_bg2_z40", "LNMS", -6.0, 3_001),
-         ("nr_bg2_z40_r1400", "LNMS", -4.5, 3_000), ("nr_bg1_z384", "LNMS", -3.75, 1_025), ("wifi648", "LNMS", -1.0, 10_000)]
+         ("nr_bg2_z40_r1400", "LNMS", -4.5, 3_000), ("nr_bg1_z384", "LNMS", -3.75, 1_025), ("wifi648", "LNMS", -1.0, 10_000),
+         # the multi-wave flooding kernels (three Z = 40 frames per workgroup; LLRs staged in a scratch slice)
+         ("nr_bg2_z40", "R1", -5.5, 6_001), ("nr_bg2_z40_r1400", "R1", -4.0, 6_000), ("nr_bg2_z40", "R0", -2.0, 4_001),
+         ("nr_bg2_z40", "OMS", -5.5, 3_002)]
 
 
 def _both(code, G, cfg, snr, frames, dtype, dev, **kw):
@@ -42,7 +45,9 @@ def test_fused_counters_equal_three_launches(name, rule, snr, frames):
             assert kernel.startswith("fused_spec_"), kernel
             assert fused.tolist() == three.tolist(), (kernel, cfg.early_exit, fused, three)
             assert fused[0] == frames
-            if cfg.early_exit and (name, rule) != ("wifi648", "R0"):   # R0 never converges on the 802.11n code
+            if name.startswith("nr_bg2") and rule != "LNMS":
+                assert kernel.startswith(("fused_spec_r0w_", "fused_spec_r1w_", "fused_spec_omsw_")), kernel
+            if cfg.early_exit and rule != "R0":   # R0 is a weak rule: it never converges on the 802.11n code
                 assert 0 < fused[1] < frames, fused        # the batch straddles the waterfall
 
 
