@@ -37,7 +37,8 @@ UNITS += [("decode_spec_spa.o", "decode_spec_spa.hip", []),
           ("decode_spec_r1w_r6.o", "decode_spec_r1w.hip", ["-DLDPC_R1W_RULE=6"]),
           ("decode_spec.o", "decode_spec.hip", []),
           ("decode_spec_h.o", "decode_spec_h.hip", []),
-          ("decode_lnms_h.o", "decode_lnms_h.hip", [])]
+          ("decode_lnms_h.o", "decode_lnms_h.hip", []),
+          ("decode_lnms_h_fused.o", "decode_lnms_h.hip", ["-DLDPC_SPEC_FUSED"])]
 UNITS += [(f"decode_qc_r{k}.o", "decode_qc.hip", [f"-DLDPC_QC_RULE={k}"]) for k in (1, 2, 3, 4, 6)]
 UNITS += [("decode_qc_r0.o", "decode_qc_r0.hip", []),
           ("decode_qc_lnms.o", "decode_qc_lnms.hip", []),

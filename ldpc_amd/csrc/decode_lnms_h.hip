@@ -34,6 +34,7 @@
 #include "lnms_plan.h"
 #include "half2_ops.h"
 #include "extra_kernels.h"
+#include "sweep_fused.h"
 
 namespace ldpc {
 
@@ -77,10 +78,17 @@ struct LnHPlan {
     }
 };
 
-template <class C, int F, int RL, int WPE>
+// FUSED: the channel in front and the error accounting behind run inside the kernel (sweep_fused.h).
+// The workgroup draws the LLRs of its 2 F frames into its own slice of `scratch` ([2 F][n] floats in
+// device memory, reused group after group) and decodes from there; a frame's bit errors against the
+// transmitted word are counted where the decode-only kernel writes its decisions out (at the test it
+// passes, or after the last sweep), the per-frame "has an error" flags meet in a second row of LDS
+// flags behind the syndrome flags.  llr and the result arrays are unused.
+template <class C, int F, int RL, int WPE, bool FUSED = false>
 __global__ void __launch_bounds__((LnLayout<C, float, F, RL>::THREADS)) __attribute__((amdgpu_waves_per_eu(WPE, 8)))
 lnms_h_kernel(int max_iters, int early_exit, float scale_f, const float *__restrict__ llr, long long frames,
-              uint8_t *__restrict__ hard_out, int *__restrict__ iters_out, uint8_t *__restrict__ conv_out)
+              uint8_t *__restrict__ hard_out, int *__restrict__ iters_out, uint8_t *__restrict__ conv_out, SweepDev sp,
+              float *scratch)
 {
     typedef LnPlan<C> PL;
     typedef LnHPlan<C> HP;
@@ -112,6 +120,16 @@ lnms_h_kernel(int max_iters, int early_exit, float scale_f, const float *__restr
         wave_slot_mask = ~0ull;
     }
     const h2 scale2 = pack_half2(scale_f, scale_f);
+    // fused: the launch adds 192 bytes of LDS behind the syndrome flags.  Nothing of the accounting lives in
+    // registers across the sweeps (the check state needs them all): per-frame outcomes and the
+    // workgroup's five counters sit in LDS and are added to with LDS atomics where a frame ends.
+    int *slot_err = slot_bad + 16;   // [2 f + h]: frame h of slot f has a bit error somewhere
+    int *slot_conv = slot_bad + 32;  // [2 f + h]: it passed a syndrome test
+    unsigned long long *wg_cnt = reinterpret_cast<unsigned long long *>(slot_bad + 48);  // frames, not converged, converged wrong, bit errors, iterations
+    if constexpr (FUSED) {
+        if (tid < 5) wg_cnt[tid] = 0ull;  // the first group's staging barrier orders this before any use
+    }
+    static_assert(!FUSED || (C::NB * C::Z) % 4 == 0, "fused: four positions per draw");
 
     const long long pairs = (frames + 1) / 2, groups = (pairs + F - 1) / F;
     for (long long grp = blockIdx.x; grp < groups; grp += gridDim.x) {
@@ -119,9 +137,17 @@ lnms_h_kernel(int max_iters, int early_exit, float scale_f, const float *__restr
         const bool act0 = lane_on && fr0 < frames, act1 = lane_on && fr1 < frames;
         // loads never depend on the flags: a lane without a frame reads the group's first frame,
         // which exists.  One scalar base address per group, 32-bit offsets per lane.
-        const char *lf = reinterpret_cast<const char *>(llr + grp * (2 * F) * n);
-        const unsigned o0 = ((fr0 < frames ? (unsigned)(2 * f) : 0u) * (unsigned)n + (unsigned)z) * 4u;  // bytes
-        const unsigned o1 = ((fr1 < frames ? (unsigned)(2 * f + 1) : 0u) * (unsigned)n + (unsigned)z) * 4u;
+        const char *lf;
+        unsigned o0, o1;  // bytes
+        if constexpr (FUSED) {  // every slot of the slice holds a frame (idle ones a copy of the last)
+            lf = reinterpret_cast<const char *>(sweep_stage_group<n, 2 * F>(sp, scratch, grp, frames));
+            o0 = ((unsigned)(2 * f) * (unsigned)n + (unsigned)z) * 4u;
+            o1 = ((unsigned)(2 * f + 1) * (unsigned)n + (unsigned)z) * 4u;
+        } else {
+            lf = reinterpret_cast<const char *>(llr + grp * (2 * F) * n);
+            o0 = ((fr0 < frames ? (unsigned)(2 * f) : 0u) * (unsigned)n + (unsigned)z) * 4u;
+            o1 = ((fr1 < frames ? (unsigned)(2 * f + 1) : 0u) * (unsigned)n + (unsigned)z) * 4u;
+        }
         const h2 clamp2 = kHalfClamp2, big2 = kHalfMax2;
         auto load_pair = [&](unsigned off) -> h2 {  // off: position inside the frame relative to z
             return pack_half2_clamped(*reinterpret_cast<const float *>(lf + (o0 + off * 4u)),
@@ -144,8 +170,11 @@ lnms_h_kernel(int max_iters, int early_exit, float scale_f, const float *__restr
             }
         });
         if constexpr (!LY::SINGLE) {
-            if (tid < 2 * F) slot_bad[tid] = 0;
+            if (tid < 2 * F) { slot_bad[tid] = 0; if constexpr (FUSED) { slot_err[tid] = 0; slot_conv[tid] = 0; } }
             __syncthreads();
+        } else if constexpr (FUSED) {
+            if (tid < 2 * F) { slot_err[tid] = 0; slot_conv[tid] = 0; }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
 
         // wx: the second state word of a long row, and the word that holds bit 14 (the hard decision
@@ -235,6 +264,58 @@ lnms_h_kernel(int max_iters, int early_exit, float scale_f, const float *__restr
             });
             if (z == 0) { iters_out[frame] = iters; conv_out[frame] = (uint8_t)conv; }
         };
+        // fused: this lane's share of the bit errors of frame h against the transmitted word, taken where
+        // write_half would store the decisions
+        auto count_half = [&](int h, long long frame) __attribute__((always_inline)) -> unsigned {
+            const int sh = 15 + 16 * h;
+            // transmitted word: scalar base of the group and a 32-bit offset formed here, as in write_half
+            // (addresses the optimiser could precompute outside the decode loop would be spilled)
+            // Without a transmitted word (all zero) the loads read the staged LLRs instead and are masked
+            // off: one straight run of code, no branch per column.
+            const unsigned refmask = sp.ref ? 1u : 0u;
+            const uint8_t *rf = sp.ref ? sp.ref + grp * (2 * F) * sp.ref_stride : reinterpret_cast<const uint8_t *>(lf);
+            unsigned ro = (sp.ref ? (unsigned)(2 * f + h) * (unsigned)sp.ref_stride : 0u) + (unsigned)z;
+            asm volatile("" : "+v"(ro));
+            unsigned zero = 0;
+            asm volatile("" : "+s"(zero));
+            rf += zero;
+            (void)frame;
+            unsigned errs = 0;
+            static_for<0, NB>([&](auto bc) {
+                if constexpr (PL::cdeg(bc) != 1) {
+                    h2 v;
+                    if constexpr (PL::shared(bc)) v = lds_get<h2>(ln_addr<-1, LY, PL::lds_index(bc), 0>(zb, zbP, zbPW));
+                    else v = load_pair(bc * Z);
+                    errs += ((v >> sh) ^ ((unsigned)rf[ro + (unsigned)(bc * Z)] & refmask)) & 1u;
+                    if constexpr (bc % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+                }
+            });
+            static_for<0, MB>([&](auto br) {
+                if constexpr (PL::priv_pos(br) >= 0) {
+                    unsigned hb;
+                    if constexpr (PL::rdeg(br) >= 2) hb = (load_bits_word(br) >> (sh - 1)) & 1u;
+                    else hb = (load_priv(br) >> sh) & 1u;
+                    errs += (hb ^ ((unsigned)rf[ro + (unsigned)(priv_index(br) - z)] & refmask)) & 1u;
+                    if constexpr (br % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+                }
+            });
+            return errs;
+        };
+        // (the closures must be inlined: one that is called would hold the check state arrays by address
+        // and move them out of registers)
+        auto count_frame = [&](int h, long long frame, int iters, int conv) __attribute__((always_inline)) {
+            const unsigned e = count_half(h, frame);
+            if (e) {
+                atomicAdd(&wg_cnt[3], (unsigned long long)e);
+                slot_err[2 * f + h] = 1;
+            }
+            if (z == 0) {
+                atomicAdd(&wg_cnt[0], 1ull);
+                if (!conv) atomicAdd(&wg_cnt[1], 1ull);
+                atomicAdd(&wg_cnt[4], (unsigned long long)iters);
+                slot_conv[2 * f + h] = conv;
+            }
+        };
 
         constexpr int NPL = PL::n_priv_layers();
         constexpr int SYN_FIRST = 2, SYN_EVERY = 6;  // block rows between looks at the outcome of the syndrome test
@@ -251,7 +332,10 @@ lnms_h_kernel(int max_iters, int early_exit, float scale_f, const float *__restr
             if (early_exit || last) {
                 // ---- syndromes of the two frames: parities of the posteriors' sign bits
                 if constexpr (!LY::SINGLE) __syncthreads();
-                if (last && early_exit) break;  // no test after the last sweep
+                // no test after the last sweep.  The fused kernel runs it all the same and ignores the outcome:
+                // the one place where frames end (and their errors are counted) sits behind it, and a second copy
+                // of that code in the loop would push the sweep out of the instruction cache
+                if constexpr (!FUSED) { if (last && early_exit) break; }
                 const bool slot_done = done0 && done1;
                 unsigned bad = 0;   // bit 15 / bit 31: a check of this lane fails in frame 0 / 1
                 bool skip = false;  // the same in all lanes of a wave
@@ -304,13 +388,32 @@ lnms_h_kernel(int max_iters, int early_exit, float scale_f, const float *__restr
                     ok1 = slot_bad[2 * f + 1] == 0;
                     static_for<0, 2 * F>([&](auto k) { any_bad |= slot_bad[k] != 0; });
                 }
-                if (last) {
-                    res_conv0 = ok0 ? 1 : 0;
-                    res_conv1 = ok1 ? 1 : 0;
-                    break;
+                if constexpr (FUSED) {
+                    // frames that end here: those that have just passed the test; after the last sweep every
+                    // frame still running (converged = the final test in fixed-work mode, never with early exit)
+                    const bool fin0 = last ? !done0 : (!done0 && ok0), fin1 = last ? !done1 : (!done1 && ok1);
+                    const int fit = last ? (early_exit ? max_iters - 1 : max_iters) : t;
+                    const int fc0 = last ? (early_exit ? 0 : (ok0 ? 1 : 0)) : 1, fc1 = last ? (early_exit ? 0 : (ok1 ? 1 : 0)) : 1;
+                    // marked unlikely: the register allocator must take its registers from this block, not
+                    // from the sweep (to it a loop inside the decode loop looks hotter than the sweep itself)
+                    if (__builtin_expect(fin0 || fin1, 0)) {
+#pragma unroll 1
+                        for (int h = 0; h < 2; ++h) {
+                            if (h ? fin1 : fin0) count_frame(h, h ? fr1 : fr0, fit, h ? fc1 : fc0);
+                        }
+                    }
+                    done0 = done0 || fin0;
+                    done1 = done1 || fin1;
+                    if (last) break;
+                } else {
+                    if (last) {
+                        res_conv0 = ok0 ? 1 : 0;
+                        res_conv1 = ok1 ? 1 : 0;
+                        break;
+                    }
+                    if (!done0 && ok0) { write_half(0, fr0, t, 1); done0 = true; }
+                    if (!done1 && ok1) { write_half(1, fr1, t, 1); done1 = true; }
                 }
-                if (!done0 && ok0) { write_half(0, fr0, t, 1); done0 = true; }
-                if (!done1 && ok1) { write_half(1, fr1, t, 1); done1 = true; }
                 if constexpr (LY::SINGLE) {
                     if (__ballot(!(done0 && done1)) == 0ull) break;
                 } else {
@@ -434,9 +537,21 @@ lnms_h_kernel(int max_iters, int early_exit, float scale_f, const float *__restr
         }
         // frames that never passed a test (or fixed work: every frame)
         const int res_iters = early_exit ? max_iters - 1 : max_iters;
-        if (act0 && !done0) write_half(0, fr0, res_iters, res_conv0);
-        if (act1 && !done1) write_half(1, fr1, res_iters, res_conv1);
+        if constexpr (!FUSED) {
+            if (act0 && !done0) write_half(0, fr0, res_iters, res_conv0);
+            if (act1 && !done1) write_half(1, fr1, res_iters, res_conv1);
+        } else {
+            // converged with an error somewhere: known once every lane of the frame has counted
+            if constexpr (LY::SINGLE) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            else __syncthreads();
+            if (tid < 2 * F && slot_conv[tid] != 0 && slot_err[tid] != 0) atomicAdd(&wg_cnt[2], 1ull);
+        }
         if constexpr (!LY::SINGLE) __syncthreads();
+    }
+    if constexpr (FUSED) {
+        if constexpr (LY::SINGLE) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        else __syncthreads();
+        if (tid < 5 && wg_cnt[tid] != 0ull) atomicAdd(&sp.counters[tid], wg_cnt[tid]);
     }
 }
 
@@ -470,12 +585,20 @@ struct LnHSlots {
     static constexpr int value = DOUBLE ? 2 * F : F;
 };
 
+#ifdef LDPC_SPEC_FUSED  // second compilation of this file: the fused-sweep instantiations (see decode_spec.hip)
+constexpr bool kFusedH = true;
+#else
+constexpr bool kFusedH = false;
+#endif
+
 template <class C, int F>
-static hipError_t launch_lnms_h(const ldpc_decode_config &cfg, const Launch &io, int num_cus, const char **name)
+static hipError_t launch_lnms_h(const ldpc_decode_config &cfg, const Launch &io, int num_cus, const char **name,
+                                const SweepDev *sp, Scratch *ws)
 {
     typedef LnHConfig<C, F> CF;
     typedef LnLayout<C, float, F, CF::RL> LY;
-    auto k = lnms_h_kernel<C, F, CF::RL, CF::WPE>;
+    auto k = lnms_h_kernel<C, F, CF::RL, CF::WPE, kFusedH>;
+    constexpr int LDS = LY::LDS_BYTES + (kFusedH ? 192 : 0);  // fused: two more rows of sixteen per-frame flags and five counters
     static int static_lds = -1;  // the kernel addresses LDS from 0: it must own the whole segment
     if (static_lds < 0) {
         hipFuncAttributes attr;
@@ -485,30 +608,51 @@ static hipError_t launch_lnms_h(const ldpc_decode_config &cfg, const Launch &io,
     }
     if (static_lds != 0) return hipErrorInvalidConfiguration;
     int per_cu = 0;
-    hipError_t e = kernel_setup(reinterpret_cast<const void *>(k), LY::THREADS, LY::LDS_BYTES, &per_cu);
+    hipError_t e = kernel_setup(reinterpret_cast<const void *>(k), LY::THREADS, LDS, &per_cu);
     if (e != hipSuccess) return e;
     if (per_cu < 1) per_cu = 1;
     if (getenv("LDPC_DEBUG_OCCUPANCY"))
         fprintf(stderr, "lnms_h_kernel<%s>: %d frame pairs per workgroup, %d block rows in registers, "
                 "%d workgroups of %d threads per CU, %d B LDS each\n",
-                C::name, F, CF::RL, per_cu, LY::THREADS, LY::LDS_BYTES);
+                C::name, F, CF::RL, per_cu, LY::THREADS, LDS);
     const long long pairs = (io.frames + 1) / 2, groups = (pairs + F - 1) / F;
-    long long grid = (long long)num_cus * (long long)per_cu * 2;
+    const long long full = (long long)num_cus * (long long)per_cu * 2;
+    long long grid = full;
     if (grid > groups) grid = groups;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(LY::THREADS), LY::LDS_BYTES, io.stream, cfg.max_iters,
+    float *scratch = nullptr;
+    if (kFusedH) {  // one slice of 2 F frames' LLRs per workgroup
+        e = scratch_reserve(*ws, (size_t)(2 * F) * C::NB * C::Z * sizeof(float), full, grid);
+        if (e != hipSuccess) return e;
+        scratch = reinterpret_cast<float *>(ws->ptr);
+    }
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(LY::THREADS), LDS, io.stream, cfg.max_iters,
                        cfg.early_exit, (float)cfg.scale, reinterpret_cast<const float *>(io.llr), io.frames,
-                       io.hard, io.iters, io.converged);
-    *name = "spec_lnms_f16x2";
+                       io.hard, io.iters, io.converged, sp ? *sp : SweepDev{}, scratch);
+    *name = kFusedH ? "fused_spec_lnms_f16x2" : "spec_lnms_f16x2";
     return hipGetLastError();
 }
 
 // Layered min-sum in packed half precision on the compiled-in codes: float LLRs, no posteriors out.
+// Compiled with -DLDPC_SPEC_FUSED the same dispatch serves ldpc_sweep_batch (channel, decode and error
+// accounting in one launch; io.llr and the result arrays unused).
+#ifdef LDPC_SPEC_FUSED
+hipError_t launch_spec_lnms_half_fused(int spec_id, const ldpc_decode_config &cfg, const Launch &io, const SweepDev &sweep,
+                                       int num_cus, Scratch &workspace, const char **name, bool *supported)
+{
+    const SweepDev *sp = &sweep;
+    Scratch *ws = &workspace;
+    *supported = false;
+    if (cfg.rule != LDPC_RULE_LNMS) return hipSuccess;
+#else
 hipError_t launch_spec_lnms_half(int spec_id, const ldpc_decode_config &cfg, const Launch &io, int num_cus,
                                  const char **name, bool *supported)
 {
+    const SweepDev *sp = nullptr;
+    Scratch *ws = nullptr;
     *supported = false;
     if (cfg.rule != LDPC_RULE_LNMS || io.llr_dtype != LDPC_F32 || io.posterior) return hipSuccess;
+#endif
     int id = 0;
 #define LDPC_LAUNCH(CODE, SLOTS)                                                                   \
     if (spec_id == id) {                                                                           \
@@ -516,7 +660,7 @@ hipError_t launch_spec_lnms_half(int spec_id, const ldpc_decode_config &cfg, con
             constexpr int FS = LnHSlots<CODE, SLOTS>::value;                                       \
             if constexpr (LnHConfig<CODE, FS>::OK) {                                               \
                 *supported = true;                                                                 \
-                return launch_lnms_h<CODE, FS>(cfg, io, num_cus, name);                            \
+                return launch_lnms_h<CODE, FS>(cfg, io, num_cus, name, sp, ws);                    \
             }                                                                                      \
         }                                                                                          \
         return hipSuccess;                                                                         \
@@ -528,7 +672,7 @@ hipError_t launch_spec_lnms_half(int spec_id, const ldpc_decode_config &cfg, con
         constexpr int FS = LnHSlots<LDPC_LNMS_DEV_ONLY, 1>::value;
         if constexpr (LnHConfig<LDPC_LNMS_DEV_ONLY, FS>::OK) {
             *supported = true;
-            return launch_lnms_h<LDPC_LNMS_DEV_ONLY, FS>(cfg, io, num_cus, name);
+            return launch_lnms_h<LDPC_LNMS_DEV_ONLY, FS>(cfg, io, num_cus, name, sp, ws);
         }
     }
 #else

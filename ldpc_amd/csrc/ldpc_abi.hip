@@ -829,7 +829,9 @@ extern "C" int32_t ldpc_sweep_batch(ldpc_code *c, const ldpc_decode_config *cfg,
     Launch io{nullptr, LDPC_F32, (long long)frames, nullptr, nullptr, nullptr, nullptr, reinterpret_cast<hipStream_t>(stream)};
     bool supported = false;
     hipError_t e = compute_dtype == LDPC_F16
-                       ? launch_spec_half_fused(c->spec_id, *cfg, io, sp, c->num_cus, &g_kernel, &supported)
+                       ? (cfg->rule == LDPC_RULE_LNMS
+                              ? launch_spec_lnms_half_fused(c->spec_id, *cfg, io, sp, c->num_cus, c->workspace_for(io.stream), &g_kernel, &supported)
+                              : launch_spec_half_fused(c->spec_id, *cfg, io, sp, c->num_cus, &g_kernel, &supported))
                        : launch_spec_fused(c->spec_id, *cfg, compute_dtype, io, sp, c->num_cus, c->workspace_for(io.stream),
                                            &g_kernel, &supported);
     if (e == hipSuccess && !supported && compute_dtype != LDPC_F16) {  // the multi-wave flooding kernels

@@ -150,15 +150,34 @@ __device__ __forceinline__ const float *sweep_stage_group(const SweepDev &sp, fl
     static_assert(N % 4 == 0, "positions are generated four at a time");
     constexpr int QUADS = N / 4;
     float *mine = scratch + (size_t)blockIdx.x * (F * N);
-    for (int i = threadIdx.x; i < F * QUADS; i += blockDim.x) {
-        const int f = F == 1 ? 0 : i / QUADS, qd = i - f * QUADS;
-        long long frame = grp * F + f;
-        if (frame >= frames) frame = frames - 1;  // idle slot: any frame that exists
-        unsigned bits = 0;
-        if (sp.ref) bits = *reinterpret_cast<const unsigned *>(sp.ref + frame * sp.ref_stride + qd * 4) & 0x01010101u;
-        float v[4];
-        channel_quad(sp.ch, sp.ch.first_frame + (unsigned long long)frame, qd, bits, v);
-        *reinterpret_cast<float4 *>(mine + f * N + qd * 4) = make_float4(v[0], v[1], v[2], v[3]);
+    // four draws per round, their transmitted bits requested together: a workgroup of these kernels has few
+    // waves per SIMD, and one load per draw would leave every draw waiting for its own memory round trip
+    constexpr int U = 4, TOTAL = F * QUADS;
+    for (int i0 = threadIdx.x; i0 < TOTAL; i0 += U * (int)blockDim.x) {
+        unsigned bits[U];
+        unsigned long long af[U];
+        int at[U], qds[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            int i = i0 + u * (int)blockDim.x;
+            if (i >= TOTAL) i = TOTAL - 1;  // past the end: a draw that exists, not stored
+            const int f = F == 1 ? 0 : i / QUADS, qd = i - f * QUADS;
+            long long frame = grp * F + f;
+            if (frame >= frames) frame = frames - 1;  // idle slot: any frame that exists
+            bits[u] = 0;
+            if (sp.ref) bits[u] = *reinterpret_cast<const unsigned *>(sp.ref + frame * sp.ref_stride + qd * 4) & 0x01010101u;
+            af[u] = sp.ch.first_frame + (unsigned long long)frame;
+            at[u] = f * N + qd * 4;
+            qds[u] = qd;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (i0 + u * (int)blockDim.x < TOTAL) {
+                float v[4];
+                channel_quad(sp.ch, af[u], qds[u], bits[u], v);
+                *reinterpret_cast<float4 *>(mine + at[u]) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
@@ -201,6 +220,9 @@ hipError_t launch_spec_r1w_fused(int spec_id, const ldpc_decode_config &cfg, int
                                  int num_cus, Scratch &workspace, const char **kernel_name, bool *supported);
 hipError_t launch_spec_omsw_fused(int spec_id, const ldpc_decode_config &cfg, int compute_dtype, const Launch &io, const SweepDev &sp,
                                   int num_cus, Scratch &workspace, const char **kernel_name, bool *supported);
+// decode_lnms_h.hip: the layered rule in packed half precision
+hipError_t launch_spec_lnms_half_fused(int spec_id, const ldpc_decode_config &cfg, const Launch &io, const SweepDev &sp,
+                                       int num_cus, Scratch &workspace, const char **kernel_name, bool *supported);
 hipError_t launch_spec_lnms_fused(int spec_id, const ldpc_decode_config &cfg, int compute_dtype, const Launch &io,
                                   const SweepDev &sp, int num_cus, Scratch &workspace, const char **kernel_name,
                                   bool *supported);

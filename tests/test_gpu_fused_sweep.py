@@ -68,6 +68,25 @@ def test_fused_half_precision_counters_equal_three_launches(frames):
             assert 0 < fused[1] < frames, fused
 
 
+@pytest.mark.parametrize("name,snr,frames", [("nr_bg1_z384", -3.75, 1_027), ("nr_bg2_z40", -6.0, 3_001),
+                                             ("nr_bg2_z40_r1400", -4.5, 2_999), ("wifi648", -1.0, 10_003), ("nr_bg1_z384", -3.75, 3)])
+def test_fused_half_precision_layered_counters_equal_three_launches(name, snr, frames):
+    """The layered rule in packed half precision: the workgroup stages the LLRs of its frame pairs in a
+    scratch slice and counts a frame's errors at the test it passes (its partner sweeps on); counters
+    equal the three launches, odd frame counts and all-zero words included."""
+    import torch
+    dev = torch.device("cuda", 0)
+    code = codes.load_packaged(name)
+    G = codes.load_packaged_generator(name) if name == "wifi648" else None
+    for cfg in (config.LNMS, config.LNMS.with_(max_iters=6, early_exit=False)):
+        kernel, fused, three = _both(code, G, cfg, snr, frames, np.float16, dev)
+        assert kernel == "fused_spec_lnms_f16x2", kernel
+        assert fused.tolist() == three.tolist(), (cfg.early_exit, fused, three)
+        assert fused[0] == frames
+        if cfg.early_exit and frames > 1000:
+            assert 0 < fused[1] < frames, fused
+
+
 def test_fused_with_prefix_doppler_and_all_zero_word():
     import torch
     from ldpc_amd import channel, sweep

@@ -26,18 +26,19 @@ def _run(dec, L, cfg, compute, kernel, noalloc):
     return name, hard.cpu().numpy(), iters.cpu().numpy(), conv.cpu().numpy(), post.cpu().numpy()
 
 
-@pytest.mark.parametrize("rule,kernel,compute,expect", [
-    ("R1", _lib.KERNEL_CSR, np.float64, "csr_global_all_f64"),
-    ("R0", _lib.KERNEL_CSR, np.float32, "csr_global_all_f32"),
-    ("LNMS", _lib.KERNEL_QC, np.float32, "qc_lnms_global_f32"),
+@pytest.mark.parametrize("rule,kernel,compute,expect,first", [
+    ("R1", _lib.KERNEL_CSR, np.float64, "csr_global_all_f64", 40),      # 14 slices of the array for 40 frame groups
+    ("R0", _lib.KERNEL_CSR, np.float32, "csr_global_all_f32", 40),
+    ("LNMS", _lib.KERNEL_QC, np.float32, "qc_lnms_global_f32", 40),
+    ("LNMS", _lib.KERNEL_QC, np.float32, "qc_lnms_global_f32", 400),    # 158 slices of 212 KB for 400 frame groups
 ])
-def test_noalloc_matches_decode_batch(rule, kernel, compute, expect):
+def test_noalloc_matches_decode_batch(rule, kernel, compute, expect, first):
     code = codes.load_packaged("nr_bg1_z384")
     dec = Decoder(code)
     cfg = config.PRESETS[rule].with_(max_iters=6)
     rng = np.random.default_rng(5)
     assert _lib.load().ldpc_noalloc_scratch_bytes() == 32 << 20
-    for frames in (40, 9):          # the second call is smaller and reuses the array as the first left it
+    for frames in (first, 9):       # the second call is smaller and reuses the array as the first left it
         L = (2.2 * (1.0 + 0.6 * rng.standard_normal((frames, code.n)))).astype(np.float32)
         if cfg.plus_is_bit:
             L = -L
