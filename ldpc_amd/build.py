@@ -35,6 +35,7 @@ UNITS += [("decode_spec_spa.o", "decode_spec_spa.hip", []),
           ("decode_spec_r1w_r1.o", "decode_spec_r1w.hip", ["-DLDPC_R1W_RULE=1"]),
           ("decode_spec_r1w_r0.o", "decode_spec_r1w.hip", ["-DLDPC_R1W_RULE=0"]),
           ("decode_spec_r1w_r6.o", "decode_spec_r1w.hip", ["-DLDPC_R1W_RULE=6"]),
+          ("decode_spec_r1m.o", "decode_spec_r1m.hip", []),
           ("decode_spec.o", "decode_spec.hip", []),
           ("decode_spec_h.o", "decode_spec_h.hip", []),
           ("decode_lnms_h.o", "decode_lnms_h.hip", []),
@@ -57,7 +58,8 @@ HEADERS = ["bp_common.h", "extra_kernels.h", "sweep_fused.h", "bp_math.h", "spec
 KERNEL_SOURCES = {"spec_lnms_f16x2": ["decode_lnms_h.hip", "lnms_plan.h", "half2_ops.h"], "spec_lnms": ["decode_lnms.hip", "lnms_plan.h"], "bg_lnms": ["decode_lnms_rt.hip", "lnms_plan.h"], "spec_r0w": ["decode_spec_r1w.hip", "spec_r1w_plan.h"],
                   "spec_r1w": ["decode_spec_r1w.hip", "spec_r1w_plan.h"], "spec_spaw": ["decode_spec_spaw.hip", "spec_r1w_plan.h"],
                   "spec_spa": ["decode_spec_spa.hip"], "spec_r0": ["decode_spec.hip"], "spec_r1": ["decode_spec.hip"],
-                  "spec_oms": ["decode_spec.hip"], "spec_r1_f16x2": ["decode_spec_h.hip", "half2_ops.h"], "spec_omsw": ["decode_spec_r1w.hip", "spec_r1w_plan.h"], "qc_lnms": ["decode_qc_lnms.hip"], "qc_r0": ["decode_qc_r0.hip"],
+                  "spec_oms": ["decode_spec.hip"], "spec_r1_f16x2": ["decode_spec_h.hip", "half2_ops.h"], "spec_omsw": ["decode_spec_r1w.hip", "spec_r1w_plan.h"],
+                  "spec_r1m": ["decode_spec_r1m.hip", "spec_r1w_plan.h"], "spec_omsm": ["decode_spec_r1m.hip", "spec_r1w_plan.h"], "qc_lnms": ["decode_qc_lnms.hip"], "qc_r0": ["decode_qc_r0.hip"],
                   "qc": ["decode_qc.hip"], "csr": ["decode_csr.hip"]}
 
 

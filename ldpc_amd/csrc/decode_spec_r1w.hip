@@ -836,26 +836,38 @@ constexpr bool r0w_wanted()
            (C::EB > 100 || (160 * 1024) / single < 8);
 }
 
+// Waves per frame group where LDS holds a single workgroup per compute unit anyway (0: four everywhere):
+// sixteen waves instead of eight hide the barriers of the BG2-shaped matrix in double (6.0 -> 7.1 Gbit/s)
+#ifndef LDPC_R0W_WAVES_BIG
+#define LDPC_R0W_WAVES_BIG 8
+#endif
+
 template <class C, int SLOTS>
 static hipError_t launch_r0w_code(const ldpc_decode_config &cfg, int compute_dtype, const Launch &io, int num_cus,
                                   const char **name, bool *supported, const SweepDev *sp = nullptr, Scratch *ws = nullptr)
 {
     *supported = true;
-    constexpr int W = 4;
     constexpr int FD = packed_slots<C, double, SLOTS, R0wLayout>(), FF = packed_slots<C, float, SLOTS, R0wLayout>();
     if constexpr (r0w_wanted<C, double, FD>()) {
+        constexpr int W = LDPC_R0W_WAVES_BIG > 0 && R0wLayout<C, double, FD>::LDS_BYTES > 80 * 1024 ? LDPC_R0W_WAVES_BIG : 4;
         if (compute_dtype == LDPC_F64) {
             if (!sp && io.llr_dtype == LDPC_F64) return launch_r0w<C, double, double, FD, W>(cfg, io, num_cus, name, supported);
             return launch_r0w<C, double, float, FD, W>(cfg, io, num_cus, name, supported, sp, ws);
         }
     }
     if constexpr (r0w_wanted<C, float, FF>()) {
+        constexpr int W = LDPC_R0W_WAVES_BIG > 0 && R0wLayout<C, float, FF>::LDS_BYTES > 80 * 1024 ? LDPC_R0W_WAVES_BIG : 4;
         if (compute_dtype == LDPC_F32 && (sp || io.llr_dtype == LDPC_F32))
             return launch_r0w<C, float, float, FF, W>(cfg, io, num_cus, name, supported, sp, ws);
     }
     *supported = false;
     return hipSuccess;
 }
+
+// decode_spec_r1m.hip: rules R1 and OMS in double with one number per edge, for codes whose frame fits LDS
+// twice that way and only once in the layout of this file; asked first
+hipError_t launch_spec_r1m(int spec_id, const ldpc_decode_config &cfg, const Launch &io, int num_cus, const char **name,
+                           bool *supported, const SweepDev *sp, Scratch *ws);
 
 // One translation unit per rule (-DLDPC_R1W_RULE=0, 1 or 6) so that they compile side by side;
 // templates the unit does not launch are never instantiated.
@@ -870,6 +882,12 @@ hipError_t launch_spec_r1w(int spec_id, const ldpc_decode_config &cfg, int compu
                            int num_cus, const char **name, bool *supported)
 #endif
 {
+#if LDPC_R1W_RULE != 0
+    if (compute_dtype == LDPC_F64) {
+        hipError_t e1 = launch_spec_r1m(spec_id, cfg, io, num_cus, name, supported, nullptr, nullptr);
+        if (e1 != hipSuccess || *supported) return e1;
+    }
+#endif
     int id = 0;
 #if LDPC_R1W_RULE == 0
 #define LDPC_LAUNCH(CODE, SLOTS)                                                                   \
@@ -898,6 +916,12 @@ hipError_t launch_spec_r1w_fused(int spec_id, const ldpc_decode_config &cfg, int
                                  int num_cus, Scratch &workspace, const char **name, bool *supported)
 #endif
 {
+#if LDPC_R1W_RULE != 0
+    if (compute_dtype == LDPC_F64) {
+        hipError_t e1 = launch_spec_r1m(spec_id, cfg, io, num_cus, name, supported, &sp, &workspace);
+        if (e1 != hipSuccess || *supported) return e1;
+    }
+#endif
     int id = 0;
 #if LDPC_R1W_RULE == 0
 #define LDPC_LAUNCH(CODE, SLOTS)                                                                   \

@@ -46,7 +46,7 @@ def test_fused_counters_equal_three_launches(name, rule, snr, frames):
             assert fused.tolist() == three.tolist(), (kernel, cfg.early_exit, fused, three)
             assert fused[0] == frames
             if name.startswith("nr_bg2") and rule != "LNMS":
-                assert kernel.startswith(("fused_spec_r0w_", "fused_spec_r1w_", "fused_spec_omsw_")), kernel
+                assert kernel.startswith(("fused_spec_r0w_", "fused_spec_r1w_", "fused_spec_omsw_", "fused_spec_r1m_", "fused_spec_omsm_")), kernel
             if cfg.early_exit and rule != "R0":   # R0 is a weak rule: it never converges on the 802.11n code
                 assert 0 < fused[1] < frames, fused        # the batch straddles the waterfall
 

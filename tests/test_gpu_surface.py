@@ -93,7 +93,7 @@ def test_loop_bound_quirks_on_gpu(c_oracle):
              ("nr_bg2_z40_r1400", config.R3.with_(num_refresh_vars=648, max_iters=4, early_exit=False)),
              ("nr_bg2_z40_r1400", config.R4.with_(num_refresh_vars=648, max_iters=10))]
     # which of them run on compiled-in kernels under the automatic choice
-    compiled = {("ccsds512", 0): "spec_r0_", ("wifi648", 0): "spec_r0_", ("nr_bg2_z40_r1400", 1): "spec_r1w_", ("nr_bg2_z40", 1): "spec_r1w_",
+    compiled = {("ccsds512", 0): "spec_r0_", ("wifi648", 0): "spec_r0_", ("nr_bg2_z40_r1400", 1): "spec_r1w_", ("nr_bg2_z40", 1): "spec_r1m_",
                 ("nr_bg2_z40_r1400", 2): "spec_spaw_", ("nr_bg2_z40_r1400", 3): "spec_spaw_", ("nr_bg2_z40_r1400", 4): "spec_spaw_"}
     decs = {}
     for name, cfg in cases:
@@ -113,7 +113,8 @@ def test_loop_bound_quirks_on_gpu(c_oracle):
                 np.testing.assert_allclose(res.posterior, ep, rtol=1e-4, atol=1e-7)
         if (name, cfg.rule) in compiled:   # the float instantiation carries the switch as well
             res = dec.decode(L.astype(np.float32), cfg, compute_dtype=np.float32)
-            assert res.kernel.startswith(compiled[(name, cfg.rule)]), res.kernel
+            # (the in-place kernel of the full 5G matrix exists in double only: float stays on the multi-wave kernel)
+            assert res.kernel.startswith(compiled[(name, cfg.rule)].replace("spec_r1m_", "spec_r1w_")), res.kernel
             assert (res.iters == ei).mean() > 0.9 and ((res.hard != eh).any(axis=1) & (res.converged & ec)).mean() < 0.05
 
 
