@@ -1,8 +1,8 @@
 // Rule R1 (bpsk.py:154-260, extrinsic normalised min-sum) and the offset rule in double precision for
-// compiled-in codes whose frame does not fit LDS twice in the layout of decode_spec_r1w.hip (the
-// BG2-shaped 5G matrix of the reference: 63 KB of messages + 27 KB of check states per frame, one
-// eight-wave workgroup per compute unit, half of its time spent waiting at the two barriers of an
-// iteration).
+// the large compiled-in base graphs (the BG2-shaped 5G matrix of the reference and its 1400-row cut,
+// channel.py:35).  In the layout of decode_spec_r1w.hip the full matrix takes 63 KB of messages + 27 KB of
+// check states per frame: one eight-wave workgroup per compute unit, half of its time spent waiting at
+// the two barriers of an iteration.
 //
 // Here a frame keeps ONE number per edge, updated in place: the variable writes its message to the
 // check, the check overwrites it with its answer (the same lane reads and writes an edge's word in each
@@ -266,13 +266,13 @@ spec_r1m_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t 
 
 // ------------------------------------------------------------------------------------------ host
 // Served: compiled-in codes of 100 to 200 base-graph edges without double-circulant blocks whose frame
-// takes more than half of LDS in the layout of spec_r1w_kernel and at most half in this one.
+// takes at most half of LDS in this layout (in the layout of spec_r1w_kernel the full 5G matrix takes more
+// than half, its 1400-row cut 77 KB: two workgroups of four waves against two of eight here, 6.3 -> 7.9
+// Gbit/s).
 template <class C>
 constexpr bool r1m_wanted()
 {
-    constexpr int r1w_bytes = C::EB * C::Z * 8 + C::MB * C::Z * 16 + C::NB * C::Z;
-    return C::Z <= 64 && C::EB > 100 && C::EB <= 200 && r1w_bytes > 80 * 1024 &&
-           R1mLayout<C, double>::LDS_BYTES <= 80 * 1024 && r1m_no_double_blocks<C>();
+    return C::Z <= 64 && C::EB > 100 && C::EB <= 200 && R1mLayout<C, double>::LDS_BYTES <= 80 * 1024 && r1m_no_double_blocks<C>();
 }
 
 template <class C, typename TL, bool OMS>

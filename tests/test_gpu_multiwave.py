@@ -35,7 +35,7 @@ EXPECT = [  # code, rule, kernel that must serve it in double
     ("wifi648", "R0", "spec_r0w_f64"), ("wifi648", "R1", "spec_r1w_f64"), ("wifi648", "R3", "spec_spaw_f64"),
     ("nr_bg2_z40", "R0", "spec_r0w_f64"), ("nr_bg2_z40", "R1", "spec_r1m_f64"),
     ("nr_bg2_z40", "R2", "spec_spaw_f64"), ("nr_bg2_z40", "R3", "spec_spaw_f64"), ("nr_bg2_z40", "R4", "spec_spaw_f64"),
-    ("nr_bg2_z40_r1400", "R0", "spec_r0w_f64"), ("nr_bg2_z40_r1400", "R1", "spec_r1w_f64"),
+    ("nr_bg2_z40_r1400", "R0", "spec_r0w_f64"), ("nr_bg2_z40_r1400", "R1", "spec_r1m_f64"),
     ("nr_bg2_z40_r1400", "R3", "spec_spaw_f64"),
 ]
 SNR = {"wifi648": -1.0, "nr_bg2_z40": -6.0, "nr_bg2_z40_r1400": -5.0}

@@ -93,7 +93,7 @@ def test_loop_bound_quirks_on_gpu(c_oracle):
              ("nr_bg2_z40_r1400", config.R3.with_(num_refresh_vars=648, max_iters=4, early_exit=False)),
              ("nr_bg2_z40_r1400", config.R4.with_(num_refresh_vars=648, max_iters=10))]
     # which of them run on compiled-in kernels under the automatic choice
-    compiled = {("ccsds512", 0): "spec_r0_", ("wifi648", 0): "spec_r0_", ("nr_bg2_z40_r1400", 1): "spec_r1w_", ("nr_bg2_z40", 1): "spec_r1m_",
+    compiled = {("ccsds512", 0): "spec_r0_", ("wifi648", 0): "spec_r0_", ("nr_bg2_z40_r1400", 1): "spec_r1m_", ("nr_bg2_z40", 1): "spec_r1m_",
                 ("nr_bg2_z40_r1400", 2): "spec_spaw_", ("nr_bg2_z40_r1400", 3): "spec_spaw_", ("nr_bg2_z40_r1400", 4): "spec_spaw_"}
     decs = {}
     for name, cfg in cases:
