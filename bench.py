@@ -453,6 +453,11 @@ def other_workloads(head, args, torch, dist, device, world, rank):
                                ("BG2_Z40_R3_f32_fixed_10", "R3", "f32")]:
         run(label, bg2, rule, dtype, -2.0, False, 32768)
     run("BG2_Z40_R1_f32_es_n0_-4dB", bg2, "R1", "f32", -4.0, True, 32768)
+    # ... and on its first 1400 rows, the matrix the reference's channel.py decodes (channel.py:35)
+    cut = Runner("nr_bg2_z40_r1400", torch, dist, device, world, rank)
+    run("BG2_Z40_rows1400_R1_f64_fixed_10", cut, "R1", "f64", -2.0, False, 32768)
+    run("BG2_Z40_rows1400_R1_f64_es_n0_-4dB", cut, "R1", "f64", -4.0, True, 32768)
+    del cut
     res.update(link_workloads(head, bg2, args, torch, dist, device, world, rank))
     return res
 
@@ -463,12 +468,16 @@ def link_workloads(head, bg2, args, torch, dist, device, world, rank):
     channel (BASELINE configuration 5), the device encoder and 5G rate recovery."""
     from ldpc_amd import channel, config, encoder, nr_rate_match, sweep
     res = {}
-    code, dec = head.code, head.dec
-    frames = min(args.frames, 1 << 19)
-    for label, rule, dtype, snr in (("sweep_R0_f64_es_n0_1dB", "R0", np.float64, 1.0), ("sweep_R1_f32_es_n0_1dB", "R1", np.float32, 1.0),
-                                    ("sweep_R1_f16x2_es_n0_1dB", "R1", np.float16, 1.0)):   # packed half precision: reduced precision
+    for label, rn, rule, dtype, snr, frames in (
+            ("sweep_R0_f64_es_n0_1dB", head, "R0", np.float64, 1.0, min(args.frames, 1 << 19)),
+            ("sweep_R1_f32_es_n0_1dB", head, "R1", np.float32, 1.0, min(args.frames, 1 << 19)),
+            ("sweep_R1_f16x2_es_n0_1dB", head, "R1", np.float16, 1.0, min(args.frames, 1 << 19)),   # packed half precision: reduced precision
+            # the large codes stage their LLRs in a scratch slice per workgroup: the fused launch saves the LLR
+            # array and its HBM traffic, not time - channel and decode are bound by vector issue alike
+            ("sweep_BG2_Z40_R1_f64_es_n0_-4dB", bg2, "R1", np.float64, -4.0, 32768)):
+        code, dec = rn.code, rn.dec
         cfg = config.PRESETS[rule].with_(max_iters=args.max_iters)
-        cw = sweep.make_codewords(code, head.G, frames, [31, rank], device)
+        cw = sweep.make_codewords(code, rn.G, frames, [31, rank], device)
         ctr = torch.zeros((5,), dtype=torch.int64, device=device)
 
         def fused():
@@ -481,7 +490,7 @@ def link_workloads(head, bg2, args, torch, dist, device, world, rank):
 
         w1, _ = timed_steps(fused, 3, 2, torch, dist, world)
         w3, _ = timed_steps(three, 3, 2, torch, dist, world)
-        res[label] = {"fused_gbit_s": frames * world * 3 * head.k / w1 / 1e9, "three_launch_gbit_s": frames * world * 3 * head.k / w3 / 1e9,
+        res[label] = {"fused_gbit_s": frames * world * 3 * rn.k / w1 / 1e9, "three_launch_gbit_s": frames * world * 3 * rn.k / w3 / 1e9,
                       "frames": frames, "code": code.name, "rule": rule, "es_n0_db": snr, "early_exit": True,
                       "hbm_bytes_per_frame_fused": code.n, "hbm_bytes_per_frame_three_launches": 11 * code.n + 10}
         del cw

@@ -38,6 +38,7 @@ BENCH_PATH = {
     "nr_bg2_z40/R0/f32/f32llr": ("other", "BG2_Z40_R0_f32_fixed_10", "gbit_s"),
     "nr_bg2_z40/R1/f64/f32llr": ("other", "BG2_Z40_R1_f64_fixed_10", "gbit_s"),
     "nr_bg2_z40/R1/f32/f32llr": ("other", "BG2_Z40_R1_f32_fixed_10", "gbit_s"),
+    "nr_bg2_z40_r1400/R1/f64/f32llr": ("other", "BG2_Z40_rows1400_R1_f64_fixed_10", "gbit_s"),
     "nr_bg2_z40/R3/f32/f32llr": ("other", "BG2_Z40_R3_f32_fixed_10", "gbit_s"),
 }
 INFO_BITS = {"ccsds512": 256, "wifi648": 324, "nr_bg2_z40": 400, "nr_bg2_z40_r1400": 680, "nr_bg1_z384": 8448}
