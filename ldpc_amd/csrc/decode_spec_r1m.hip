@@ -176,9 +176,12 @@ spec_r1m_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t 
                             });
                             if constexpr (D < 2) { m1 = (T)0; m2 = (T)0; }  // bpsk.py:216
                             if (!last) {
+                                // the two magnitudes a check can answer with, formed once (the same products
+                                // as scaling the selected minimum edge by edge)
+                                const T a1 = OMS ? oms_magnitude(m1, g.scale, g.offset) : g.scale * m1;
+                                const T a2 = OMS ? oms_magnitude(m2, g.scale, g.offset) : g.scale * m2;
                                 static_for<0, D>([&](auto p) {
-                                    const T sel = t_abs(v[p]) == m1 ? m2 : m1;
-                                    const T mag = OMS ? oms_magnitude(sel, g.scale, g.offset) : g.scale * sel;
+                                    const T mag = t_abs(v[p]) == m1 ? a2 : a1;
                                     *reinterpret_cast<T *>(qv_b + off[p]) =
                                         SNum<T>::flip_sign(mag, (sx ^ SNum<T>::sign_word(v[p])) & 0x80000000u);
                                 });
