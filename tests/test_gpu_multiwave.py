@@ -94,6 +94,23 @@ def test_float32_variants_are_served_and_converge():
         assert np.array_equal(res.hard[:, checked], cw.astype(np.uint8)[:, checked])
 
 
+@pytest.mark.parametrize("name,snr", [("nr_bg2_z40", -5.5), ("nr_bg2_z40_r1400", -4.5)])
+def test_in_place_kernel_many_frames_per_workgroup(name, snr, c_oracle):
+    """The double-precision R1 / OMS kernel with one number per edge (two workgroups per compute unit, every
+    workgroup walking many frames): bit-identical to the CPU restatement on a batch across the waterfall,
+    with the reference's 30 iterations and in fixed-work mode, posteriors included."""
+    for rule in ("R1", "OMS"):
+        for cfg in (config.PRESETS[rule], config.PRESETS[rule].with_(max_iters=7, early_exit=False)):
+            code, L = noisy_llrs(name, cfg, 4099, snr, 41)
+            eh, ei, ec, ep = c_oracle.c_decode(code, cfg, L)
+            res = decoder_for(name).decode(L, cfg, compute_dtype=np.float64, want_posterior=True)
+            assert res.kernel == ("spec_r1m_f64" if rule == "R1" else "spec_omsm_f64")
+            assert np.array_equal(res.iters, ei) and np.array_equal(res.converged, ec)
+            assert np.array_equal(res.hard, eh) and np.array_equal(res.posterior, ep)
+            if cfg.early_exit:
+                assert 0.02 < 1.0 - ec.mean() < 0.9, ec.mean()   # the batch straddles the waterfall
+
+
 def test_empty_batch():
     cfg = config.PRESETS["R1"]
     code = codes.load_packaged("nr_bg2_z40")
