@@ -112,6 +112,14 @@ def build(force: bool = False, jobs: int = 8, verbose: bool = True) -> str:
     from . import gen_codes
     gen_codes.generate()
     headers = [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
+    objs = [os.path.join(OBJ, obj) for obj, _, _ in UNITS]
+    sources = sorted({os.path.join(CSRC, src) for _, src, _ in UNITS}) + headers
+    if not force and os.path.exists(LIB) and not any(os.path.exists(o) for o in objs) and not _stale(LIB, sources):
+        # a tree that travelled with the built library but without the objects (they are not shipped):
+        # the library is newer than every source, there is nothing to do
+        if verbose:
+            print("up to date", LIB, flush=True)
+        return LIB
     todo = []
     for obj, src, extra in UNITS:
         o, s = os.path.join(OBJ, obj), os.path.join(CSRC, src)
@@ -130,7 +138,6 @@ def build(force: bool = False, jobs: int = 8, verbose: bool = True) -> str:
 
     with ThreadPoolExecutor(max_workers=max(1, jobs)) as pool:
         list(pool.map(run, todo))
-    objs = [os.path.join(OBJ, obj) for obj, _, _ in UNITS]
     if force or todo or _stale(LIB, objs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
         r = subprocess.run(cmd, capture_output=True, text=True)
