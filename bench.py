@@ -445,6 +445,12 @@ def other_workloads(head, args, torch, dist, device, world, rank):
     ]:
         run(label, head, rule, dtype, snr, early, frames if rule != "R3" else frames // 4)
     run("R3_f64_fixed_10", head, "R3", "f64", 1.0, False, frames // 8)
+    # BASELINE configuration 1: the small code of Matrices/H.txt (802.11n (648,324)), 65 536 frames, min-sum
+    wifi = Runner("wifi648", torch, dist, device, world, rank)
+    run("WIFI648_R1_f64_fixed_10", wifi, "R1", "f64", 1.0, False, 65536)
+    run("WIFI648_R1_f32_fixed_10", wifi, "R1", "f32", 1.0, False, 65536)
+    run("WIFI648_R1_f64_es_n0_1dB", wifi, "R1", "f64", 1.0, True, 65536)
+    del wifi
     # the flooding rules on the BG2-shaped 5G matrix of the reference (all-zero codeword: these rules are
     # symmetric in the codeword)
     bg2 = Runner("nr_bg2_z40", torch, dist, device, world, rank)
