@@ -355,9 +355,9 @@ int32_t ldpc_rate_recover(const ldpc_rate_match_config *cfg, const void *llr_dev
  * ldpc_count_errors: the five numbers added to counters_dev equal, bit for bit, what the three
  * calls in a row add for the same arguments.  ref_dev: transmitted codewords [frames, n]
  * (ref_stride = n), one codeword for all frames (ref_stride = 0) or NULL (the all-zero codeword);
- * 4-byte aligned.  Served for the compiled-in codes (rules R0, R1, OMS on the small ones, LNMS on
- * all, in LDPC_F32 / LDPC_F64; rule R1 on the small ones in LDPC_F16); LDPC_ERR_UNSUPPORTED
- * otherwise, and the three calls are the fallback.
+ * 4-byte aligned.  Served for the compiled-in codes (rules R0, R1, OMS and LNMS in LDPC_F32 / LDPC_F64;
+ * rule R1 on the small ones and LNMS in LDPC_F16); LDPC_ERR_UNSUPPORTED otherwise (sum-product rules,
+ * matrices that are not compiled in, loop-bound quirks), and the three calls are the fallback.
  */
 typedef struct ldpc_channel_config {
     double sigma2;                 /* noise variance, 1 / (2 * 10^(SNR/10)), ldpc.py:245 */
@@ -373,6 +373,19 @@ typedef struct ldpc_channel_config {
 int32_t ldpc_sweep_batch(ldpc_code *code, const ldpc_decode_config *cfg, const ldpc_channel_config *channel,
                          const uint8_t *ref_dev, int64_t ref_stride, int64_t frames, int32_t compute_dtype,
                          uint64_t *counters_dev, void *stream);
+/*
+ * The same with the transmitted codewords as bits: position i of a frame is bit (i & 7) of byte i >> 3 of
+ * its word, words ref_stride_bytes apart (>= (n + 7) / 8; 0 = one word for all frames; NULL = all zero),
+ * no alignment requirement: n / 8 bytes of device memory traffic per frame instead of n.  Counters are
+ * identical to ldpc_sweep_batch on the same words.  ldpc_pack_bits turns words of one byte per bit (what
+ * ldpc_encode_batch writes) into this form; the low bit of each byte counts.  Neither has a counterpart
+ * in the reference, whose codewords are numpy integer arrays (ldpc.py:46).
+ */
+int32_t ldpc_sweep_batch_packed(ldpc_code *code, const ldpc_decode_config *cfg, const ldpc_channel_config *channel,
+                                const uint8_t *ref_bits_dev, int64_t ref_stride_bytes, int64_t frames,
+                                int32_t compute_dtype, uint64_t *counters_dev, void *stream);
+int32_t ldpc_pack_bits(const uint8_t *bytes_dev, int64_t stride, int64_t frames, int32_t n, uint8_t *bits_dev,
+                       int64_t bits_stride, void *stream);
 
 /*
  * One batch that mixes frames of several codes (e.g. CCSDS and 5G frames of one link), decoded by

@@ -20,7 +20,7 @@ KERNEL_AUTO, KERNEL_CSR, KERNEL_QC, KERNEL_GRAPH = 0, 1, 2, 3
 #: every symbol include/ldpc_amd.h declares
 SYMBOLS = ["ldpc_last_error", "ldpc_abi_version", "ldpc_device_count", "ldpc_code_create_csr",
            "ldpc_code_attach_qc", "ldpc_code_destroy", "ldpc_code_info", "ldpc_decode_batch",
-           "ldpc_decode_batch_host", "ldpc_decode_batch_noalloc", "ldpc_noalloc_scratch_bytes", "ldpc_code_workspace_bytes", "ldpc_count_errors", "ldpc_allreduce_counters", "ldpc_channel_llr", "ldpc_channel_llr_doppler", "ldpc_decode_segments", "ldpc_sweep_batch", "ldpc_encoder_create", "ldpc_encoder_destroy", "ldpc_encode_batch", "ldpc_encode_random", "ldpc_rate_match", "ldpc_rate_recover",
+           "ldpc_decode_batch_host", "ldpc_decode_batch_noalloc", "ldpc_noalloc_scratch_bytes", "ldpc_code_workspace_bytes", "ldpc_count_errors", "ldpc_allreduce_counters", "ldpc_channel_llr", "ldpc_channel_llr_doppler", "ldpc_decode_segments", "ldpc_sweep_batch", "ldpc_sweep_batch_packed", "ldpc_pack_bits", "ldpc_encoder_create", "ldpc_encoder_destroy", "ldpc_encode_batch", "ldpc_encode_random", "ldpc_rate_match", "ldpc_rate_recover",
            "ldpc_last_kernel"]
 
 
@@ -139,6 +139,10 @@ def load() -> ctypes.CDLL:
     lib.ldpc_rate_recover.argtypes = [ctypes.POINTER(CRateMatchConfig), vp, i32, i64, ctypes.c_double, i32, vp, i32, vp]
     lib.ldpc_sweep_batch.restype = i32
     lib.ldpc_sweep_batch.argtypes = [vp, ctypes.POINTER(CDecodeConfig), ctypes.POINTER(CChannelConfig), vp, i64, i64, i32, vp, vp]
+    lib.ldpc_sweep_batch_packed.restype = i32
+    lib.ldpc_sweep_batch_packed.argtypes = lib.ldpc_sweep_batch.argtypes
+    lib.ldpc_pack_bits.restype = i32
+    lib.ldpc_pack_bits.argtypes = [vp, i64, i64, i32, vp, i64, vp]
     lib.ldpc_decode_segments.restype = i32
     lib.ldpc_decode_segments.argtypes = [ctypes.POINTER(CSegment), i32, ctypes.POINTER(CDecodeConfig), i32, i32, i32]
     _lib = lib

@@ -4,6 +4,7 @@
 // other than the reference, [3] += codeword-bit errors over all n bits, [4] += sum of iters.
 // One wave per frame at a time; per-workgroup partial sums, then one atomic per counter.
 #include "bp_common.h"
+#include "extra_kernels.h"
 
 namespace ldpc {
 
@@ -50,6 +51,35 @@ hipError_t launch_count_errors(const uint8_t *hard, const uint8_t *ref, long lon
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(count_errors_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, hard, ref,
                        ref_stride, iters, conv, frames, n, counters);
+    return hipGetLastError();
+}
+
+// One thread per output byte: positions 8 i .. 8 i + 7 of a frame, lowest bit first; positions beyond n are 0.
+__global__ void pack_bits_kernel(const uint8_t *__restrict__ bytes, long long stride, long long frames, int n,
+                                 uint8_t *__restrict__ bits, long long bits_stride)
+{
+    const int per = (n + 7) / 8;
+    const long long total = frames * per;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long f = i / per;
+        const int b = (int)(i - f * per);
+        unsigned v = 0;
+        for (int k = 0; k < 8; ++k) {
+            const int pos = 8 * b + k;
+            if (pos < n) v |= (unsigned)(bytes[f * stride + pos] & 1u) << k;
+        }
+        bits[f * bits_stride + b] = (uint8_t)v;
+    }
+}
+
+hipError_t launch_pack_bits(const uint8_t *bytes, long long stride, long long frames, int n, uint8_t *bits,
+                            long long bits_stride, hipStream_t stream)
+{
+    const long long total = frames * ((n + 7) / 8);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(pack_bits_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, bytes, stride, frames, n, bits, bits_stride);
     return hipGetLastError();
 }
 

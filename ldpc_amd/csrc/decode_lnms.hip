@@ -78,7 +78,6 @@ lnms_body(const Cfg<T> &g, const TL *__restrict__ llr, long long frames, uint8_t
     volatile int *slot_bad_now = slot_bad;  // polled while other waves may still be writing
     int *slot_err = slot_bad + 8;           // fused: the slot's frame has a bit error somewhere
     SweepAcc acc;
-    float *my_scratch = FUSED ? scratch + (size_t)blockIdx.x * (F * n) : nullptr;
 
     const long long groups = (frames + F - 1) / F;
     for (long long grp = blockIdx.x; grp < groups; grp += gridDim.x) {
@@ -88,22 +87,11 @@ lnms_body(const Cfg<T> &g, const TL *__restrict__ llr, long long frames, uint8_t
         // frame is the same for every lane (a scalar base address), the rest is a 32-bit offset.
         const TL *lf;
         unsigned fo;
+        const uint8_t *ref_slice = nullptr;  // fused: the frames' transmitted bits, [F][n] bytes
         if constexpr (FUSED) {
-            // channel LLRs of the group's frames, four positions per draw, into this workgroup's slice
-            constexpr int QUADS = n / 4;
-            for (int i = tid; i < F * QUADS; i += LY::THREADS) {
-                const int f2 = F == 1 ? 0 : i / QUADS, qd = i - f2 * QUADS;
-                long long fr = grp * F + f2;
-                if (fr >= frames) fr = frames - 1;  // idle slot: any frame that exists
-                unsigned bits = 0;
-                if (sp.ref) bits = *reinterpret_cast<const unsigned *>(sp.ref + fr * sp.ref_stride + qd * 4) & 0x01010101u;
-                float v[4];
-                channel_quad(sp.ch, sp.ch.first_frame + (unsigned long long)fr, qd, bits, v);
-                *reinterpret_cast<float4 *>(my_scratch + f2 * n + qd * 4) = make_float4(v[0], v[1], v[2], v[3]);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            if constexpr (!LY::SINGLE) __syncthreads();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            // channel LLRs (and transmitted bits) of the group's frames into this workgroup's slice
+            const float *my_scratch = sweep_stage_group<n, F>(sp, scratch, grp, frames);
+            ref_slice = sweep_slice_ref<n, F>(my_scratch);
             lf = reinterpret_cast<const TL *>(my_scratch);
             fo = (unsigned)f * (unsigned)n + (unsigned)z;
         } else {
@@ -233,14 +221,14 @@ lnms_body(const Cfg<T> &g, const TL *__restrict__ llr, long long frames, uint8_t
 
         // fused: this lane's share of the frame's bit errors against the transmitted word
         auto count_errs = [&]() -> unsigned {
-            const uint8_t *rf = sp.ref ? sp.ref + frame * sp.ref_stride : nullptr;
+            const uint8_t *rf = ref_slice + (unsigned)f * (unsigned)n;
             unsigned errs = 0;
             static_for<0, NB>([&](auto bc) {
                 if constexpr (PL::cdeg(bc) != 1) {
                     T v;
                     if constexpr (PL::shared(bc)) v = lds_get<T>(ln_addr<WV, LY, PL::lds_index(bc), 0>(zb, zbP, zbPW));
                     else v = (T)lf[fo + (unsigned)(bc * Z)] + (T)0;
-                    errs += hard_bit<1>(v) != (rf ? (unsigned)rf[bc * Z + z] : 0u);
+                    errs += hard_bit<1>(v) != (unsigned)rf[bc * Z + z];
                 }
             });
             static_for<0, MB>([&](auto br) {
@@ -254,7 +242,7 @@ lnms_body(const Cfg<T> &g, const TL *__restrict__ llr, long long frames, uint8_t
                     } else {
                         hb = hard_bit<1>(load_priv(br));
                     }
-                    errs += hb != (rf ? (unsigned)rf[priv_index(br)] : 0u);
+                    errs += hb != (unsigned)rf[priv_index(br)];
                 }
             });
             return errs;
@@ -534,7 +522,7 @@ static hipError_t launch_lnms(const ldpc_decode_config &cfg, const Launch &io, i
     if (grid < 1) grid = 1;
     float *scratch = nullptr;
     if (kFused) {  // one slice of F frames' LLRs per workgroup
-        e = scratch_reserve(*ws, (size_t)F * C::NB * C::Z * sizeof(float), full, grid);
+        e = scratch_reserve(*ws, sweep_slice_bytes<C::NB * C::Z, F>(), full, grid);
         if (e != hipSuccess) return e;
         scratch = reinterpret_cast<float *>(ws->ptr);
     }

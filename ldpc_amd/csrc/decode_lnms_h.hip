@@ -270,11 +270,10 @@ lnms_h_kernel(int max_iters, int early_exit, float scale_f, const float *__restr
             const int sh = 15 + 16 * h;
             // transmitted word: scalar base of the group and a 32-bit offset formed here, as in write_half
             // (addresses the optimiser could precompute outside the decode loop would be spilled)
-            // Without a transmitted word (all zero) the loads read the staged LLRs instead and are masked
-            // off: one straight run of code, no branch per column.
-            const unsigned refmask = sp.ref ? 1u : 0u;
-            const uint8_t *rf = sp.ref ? sp.ref + grp * (2 * F) * sp.ref_stride : reinterpret_cast<const uint8_t *>(lf);
-            unsigned ro = (sp.ref ? (unsigned)(2 * f + h) * (unsigned)sp.ref_stride : 0u) + (unsigned)z;
+            // The word is the copy the staging step put behind the group's LLRs: one straight run of code, no
+            // branch per column.
+            const uint8_t *rf = sweep_slice_ref<n, 2 * F>(reinterpret_cast<const float *>(lf));
+            unsigned ro = (unsigned)(2 * f + h) * (unsigned)n + (unsigned)z;
             asm volatile("" : "+v"(ro));
             unsigned zero = 0;
             asm volatile("" : "+s"(zero));
@@ -286,7 +285,7 @@ lnms_h_kernel(int max_iters, int early_exit, float scale_f, const float *__restr
                     h2 v;
                     if constexpr (PL::shared(bc)) v = lds_get<h2>(ln_addr<-1, LY, PL::lds_index(bc), 0>(zb, zbP, zbPW));
                     else v = load_pair(bc * Z);
-                    errs += ((v >> sh) ^ ((unsigned)rf[ro + (unsigned)(bc * Z)] & refmask)) & 1u;
+                    errs += ((v >> sh) ^ (unsigned)rf[ro + (unsigned)(bc * Z)]) & 1u;
                     if constexpr (bc % 4 == 3) __builtin_amdgcn_sched_barrier(0);
                 }
             });
@@ -295,7 +294,7 @@ lnms_h_kernel(int max_iters, int early_exit, float scale_f, const float *__restr
                     unsigned hb;
                     if constexpr (PL::rdeg(br) >= 2) hb = (load_bits_word(br) >> (sh - 1)) & 1u;
                     else hb = (load_priv(br) >> sh) & 1u;
-                    errs += (hb ^ ((unsigned)rf[ro + (unsigned)(priv_index(br) - z)] & refmask)) & 1u;
+                    errs += (hb ^ (unsigned)rf[ro + (unsigned)(priv_index(br) - z)]) & 1u;
                     if constexpr (br % 4 == 3) __builtin_amdgcn_sched_barrier(0);
                 }
             });
@@ -622,7 +621,7 @@ static hipError_t launch_lnms_h(const ldpc_decode_config &cfg, const Launch &io,
     if (grid < 1) grid = 1;
     float *scratch = nullptr;
     if (kFusedH) {  // one slice of 2 F frames' LLRs per workgroup
-        e = scratch_reserve(*ws, (size_t)(2 * F) * C::NB * C::Z * sizeof(float), full, grid);
+        e = scratch_reserve(*ws, sweep_slice_bytes<C::NB * C::Z, 2 * F>(), full, grid);
         if (e != hipSuccess) return e;
         scratch = reinterpret_cast<float *>(ws->ptr);
     }

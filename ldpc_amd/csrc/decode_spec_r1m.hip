@@ -233,13 +233,13 @@ spec_r1m_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t 
         if constexpr (FUSED) {
             unsigned errs = 0;
             if (lane_on) {
-                const uint8_t *rf = sp.ref ? sp.ref + frame * sp.ref_stride : nullptr;
+                const uint8_t *rf = sweep_slice_ref<n, 1>(mine);  // the frame's transmitted bits, staged beside its LLRs
                 static_for<0, W>([&](auto w) {
                     if (wave == w) {
                         static_for<0, NBW>([&](auto j) {
                             if constexpr (j < PL::COLS.cnt[w]) {
                                 constexpr int bc = PL::COLS.col[w][j];
-                                errs += hard_bit<1>(own[j]) != (rf ? (unsigned)rf[bc * Z + z] : 0u);
+                                errs += hard_bit<1>(own[j]) != (unsigned)rf[bc * Z + z];
                             }
                         });
                     }
@@ -301,7 +301,7 @@ static hipError_t launch_r1m(const ldpc_decode_config &cfg, const Launch &io, in
         if (grid < 1) grid = 1;
         float *scratch = nullptr;
         if (fused) {
-            e = scratch_reserve(*ws, (size_t)C::NB * C::Z * sizeof(float), full, grid);
+            e = scratch_reserve(*ws, sweep_slice_bytes<C::NB * C::Z, 1>(), full, grid);
             if (e != hipSuccess) return e;
             scratch = reinterpret_cast<float *>(ws->ptr);
         }

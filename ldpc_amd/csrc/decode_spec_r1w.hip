@@ -36,7 +36,7 @@ struct R1wLayout {
 // channel.py:241): variables from g.num_refresh_vars on keep sending their channel value.  A switch of
 // its own so that the plain kernel does not pay the comparison and the selects.
 // FUSED: channel in front and error accounting behind inside the kernel (sweep_fused.h).  The workgroup
-// draws the LLRs of its F frames into its own slice of `scratch` ([F][n] floats in device memory,
+// draws the LLRs of its F frames into its own slice of `scratch` ([F][n] floats + [F][n] reference bytes in device memory,
 // reused group after group, hence cache-resident: beside three frames' messages LDS has no room for
 // them) and decodes from there; every lane counts the bit errors of the variables it owns against the
 // transmitted word, the per-frame flags meet in LDS.  llr and the result arrays are unused.
@@ -214,13 +214,13 @@ spec_r1w_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t 
         if constexpr (FUSED) {
             unsigned errs = 0;
             if (active) {
-                const uint8_t *rf = sp.ref ? sp.ref + frame * sp.ref_stride : nullptr;
+                const uint8_t *rf = sweep_slice_ref<n, F>(mine) + f * n;  // the frame's transmitted bits, staged beside its LLRs
                 static_for<0, W>([&](auto w) {
                     if (wave == w) {
                         static_for<0, NBW>([&](auto j) {
                             if constexpr (j < PL::COLS.cnt[w]) {
                                 constexpr int bc = PL::COLS.item[w][j];
-                                errs += hard_bit<1>(own[j]) != (rf ? (unsigned)rf[bc * Z + z] : 0u);
+                                errs += hard_bit<1>(own[j]) != (unsigned)rf[bc * Z + z];
                             }
                         });
                     }
@@ -616,7 +616,7 @@ spec_r0w_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t 
         if constexpr (FUSED) {
             unsigned errs = 0;
             if (active) {
-                const uint8_t *rf = sp.ref ? sp.ref + frame * sp.ref_stride : nullptr;
+                const uint8_t *rf = sweep_slice_ref<n, F>(mine) + f * n;  // the frame's transmitted bits, staged beside its LLRs
                 static_for<0, W>([&](auto w) {
                     if (wave == w) {
                         static_for<0, NBW>([&](auto j) {
@@ -624,7 +624,7 @@ spec_r0w_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t 
                                 constexpr int bc = PL::COLS.item[w][j];
                                 const T v = own[j];
                                 const unsigned hv = float_hard ? (v == (T)0 ? 0u : (v == (T)1 ? 1u : 2u)) : hard_bit<0>(v);
-                                errs += hv != (rf ? (unsigned)rf[bc * Z + z] : 0u);
+                                errs += hv != (unsigned)rf[bc * Z + z];
                             }
                         });
                     }
@@ -701,7 +701,7 @@ static hipError_t launch_r1w(const ldpc_decode_config &cfg, const Launch &io, in
             const long long groups = (io.frames + F - 1) / F, full = (long long)num_cus * per_cu * 2;
             long long grid = full > groups ? groups : full;
             if (grid < 1) grid = 1;
-            e = scratch_reserve(*ws, (size_t)F * C::NB * C::Z * sizeof(float), full, grid);
+            e = scratch_reserve(*ws, sweep_slice_bytes<C::NB * C::Z, F>(), full, grid);
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(64 * W * G), LY::LDS_BYTES, io.stream, g, nullptr, io.frames, nullptr,
                                nullptr, nullptr, nullptr, *sp, reinterpret_cast<float *>(ws->ptr));
@@ -799,7 +799,7 @@ static hipError_t launch_r0w(const ldpc_decode_config &cfg, const Launch &io, in
             const long long groups = (io.frames + F - 1) / F, full = (long long)num_cus * per_cu * 2;
             long long grid = full > groups ? groups : full;
             if (grid < 1) grid = 1;
-            e = scratch_reserve(*ws, (size_t)F * C::NB * C::Z * sizeof(float), full, grid);
+            e = scratch_reserve(*ws, sweep_slice_bytes<C::NB * C::Z, F>(), full, grid);
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(64 * W * G), LY::LDS_BYTES, io.stream, g, nullptr, io.frames, nullptr,
                                nullptr, nullptr, nullptr, *sp, reinterpret_cast<float *>(ws->ptr));

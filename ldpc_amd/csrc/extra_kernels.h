@@ -34,4 +34,9 @@ hipError_t launch_rate_match(const ldpc_rate_match_config &c, const uint8_t *cw,
 hipError_t launch_rate_recover(const ldpc_rate_match_config &c, const void *llr, int llr_dtype, long long frames,
                                double filler_llr, int accumulate, void *out, int out_dtype, hipStream_t stream);
 
+// count_errors.hip: words of one byte per bit -> eight positions per byte, lowest bit first (the packed
+// reference words of ldpc_sweep_batch_packed)
+hipError_t launch_pack_bits(const uint8_t *bytes, long long stride, long long frames, int n, uint8_t *bits,
+                            long long bits_stride, hipStream_t stream);
+
 }  // namespace ldpc

@@ -797,9 +797,9 @@ extern "C" int32_t ldpc_rate_recover(const ldpc_rate_match_config *cfg, const vo
     return LDPC_OK;
 }
 
-extern "C" int32_t ldpc_sweep_batch(ldpc_code *c, const ldpc_decode_config *cfg, const ldpc_channel_config *ch,
-                                    const uint8_t *ref_dev, int64_t ref_stride, int64_t frames, int32_t compute_dtype,
-                                    uint64_t *counters_dev, void *stream)
+static int sweep_impl(ldpc_code *c, const ldpc_decode_config *cfg, const ldpc_channel_config *ch,
+                      const uint8_t *ref_dev, int64_t ref_stride, bool packed, int64_t frames, int32_t compute_dtype,
+                      uint64_t *counters_dev, void *stream)
 {
     if (!c) return fail(LDPC_ERR_ARG, "code is NULL");
     if (int rc = check_cfg(cfg)) return rc;
@@ -808,8 +808,13 @@ extern "C" int32_t ldpc_sweep_batch(ldpc_code *c, const ldpc_decode_config *cfg,
     if (compute_dtype != LDPC_F32 && compute_dtype != LDPC_F64 && compute_dtype != LDPC_F16)
         return fail(LDPC_ERR_ARG, "dtype must be LDPC_F32, LDPC_F64 or LDPC_F16");
     if (!counters_dev) return fail(LDPC_ERR_ARG, "NULL buffer");
-    if (ref_dev && ref_stride != 0 && ref_stride != c->n) return fail(LDPC_ERR_ARG, "ref_stride must be 0 or n");
-    if (ref_dev && (reinterpret_cast<uintptr_t>(ref_dev) & 3u)) return fail(LDPC_ERR_ARG, "ref_dev must be 4-byte aligned");
+    if (packed) {
+        if (ref_dev && ref_stride != 0 && ref_stride < (c->n + 7) / 8)
+            return fail(LDPC_ERR_ARG, "ref_stride must be 0 or at least (n + 7) / 8 bytes");
+    } else {
+        if (ref_dev && ref_stride != 0 && ref_stride != c->n) return fail(LDPC_ERR_ARG, "ref_stride must be 0 or n");
+        if (ref_dev && (reinterpret_cast<uintptr_t>(ref_dev) & 3u)) return fail(LDPC_ERR_ARG, "ref_dev must be 4-byte aligned");
+    }
     if (!(ch->sigma2 >= 0.0) || ch->prefix_len < 0) return fail(LDPC_ERR_ARG, "negative noise variance or prefix length");
     if (!(ch->cfo_cycles_per_symbol > -0.5 && ch->cfo_cycles_per_symbol < 0.5) || !(ch->phase0_cycles > -128.0 && ch->phase0_cycles < 128.0))
         return fail(LDPC_ERR_ARG, "frequency offset must lie within half a cycle per symbol, phase within 128 cycles");
@@ -825,6 +830,7 @@ extern "C" int32_t ldpc_sweep_batch(ldpc_code *c, const ldpc_decode_config *cfg,
                              ch->first_frame, ch->cfo_cycles_per_symbol, ch->phase0_cycles);
     sp.ref = ref_dev;
     sp.ref_stride = ref_dev ? ref_stride : 0;
+    sp.ref_packed = packed ? 1 : 0;
     sp.counters = reinterpret_cast<unsigned long long *>(counters_dev);
     Launch io{nullptr, LDPC_F32, (long long)frames, nullptr, nullptr, nullptr, nullptr, reinterpret_cast<hipStream_t>(stream)};
     bool supported = false;
@@ -843,6 +849,32 @@ extern "C" int32_t ldpc_sweep_batch(ldpc_code *c, const ldpc_decode_config *cfg,
     if (!supported)
         return fail(LDPC_ERR_UNSUPPORTED, "no fused sweep kernel for this code, rule and arithmetic; "
                                           "use ldpc_channel_llr + ldpc_decode_batch + ldpc_count_errors");
+    return LDPC_OK;
+}
+
+extern "C" int32_t ldpc_sweep_batch(ldpc_code *c, const ldpc_decode_config *cfg, const ldpc_channel_config *ch,
+                                    const uint8_t *ref_dev, int64_t ref_stride, int64_t frames, int32_t compute_dtype,
+                                    uint64_t *counters_dev, void *stream)
+{
+    return sweep_impl(c, cfg, ch, ref_dev, ref_stride, false, frames, compute_dtype, counters_dev, stream);
+}
+
+extern "C" int32_t ldpc_sweep_batch_packed(ldpc_code *c, const ldpc_decode_config *cfg, const ldpc_channel_config *ch,
+                                           const uint8_t *ref_bits_dev, int64_t ref_stride_bytes, int64_t frames,
+                                           int32_t compute_dtype, uint64_t *counters_dev, void *stream)
+{
+    return sweep_impl(c, cfg, ch, ref_bits_dev, ref_stride_bytes, true, frames, compute_dtype, counters_dev, stream);
+}
+
+extern "C" int32_t ldpc_pack_bits(const uint8_t *bytes_dev, int64_t stride, int64_t frames, int32_t n, uint8_t *bits_dev,
+                                  int64_t bits_stride, void *stream)
+{
+    if (frames < 0 || n < 0) return fail(LDPC_ERR_ARG, "negative size");
+    if (frames == 0 || n == 0) return LDPC_OK;
+    if (!bytes_dev || !bits_dev) return fail(LDPC_ERR_ARG, "NULL buffer");
+    if (stride < n || bits_stride < (n + 7) / 8) return fail(LDPC_ERR_ARG, "stride shorter than a word");
+    hipError_t e = launch_pack_bits(bytes_dev, stride, frames, n, bits_dev, bits_stride, reinterpret_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(LDPC_ERR_HIP, "pack_bits launch: %s", hipGetErrorString(e));
     return LDPC_OK;
 }
 

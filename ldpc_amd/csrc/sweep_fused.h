@@ -79,7 +79,21 @@ struct SweepDev {
     const uint8_t *ref;            // transmitted codewords [frames, n] (ref_stride = n), one word for all
     long long ref_stride;          //   frames (ref_stride = 0), or NULL = the all-zero word
     unsigned long long *counters;  // [5], added to atomically: see count_errors.hip
+    int ref_packed;                // the words are bits, eight positions per byte, lowest bit first; ref_stride in bytes
 };
+
+// The transmitted bits of positions 4 qd .. 4 qd + 3 of a frame, one per byte of the result.  Every kernel
+// reads the reference word here and nowhere else: what the accounting compares with is the copy the
+// staging step keeps beside the LLRs.
+__device__ __forceinline__ unsigned sweep_ref_quad(const SweepDev &sp, long long frame, int qd)
+{
+    if (!sp.ref) return 0u;
+    if (sp.ref_packed) {
+        const unsigned nib = ((unsigned)sp.ref[frame * sp.ref_stride + (qd >> 1)] >> ((qd & 1) * 4)) & 15u;
+        return (nib & 1u) | ((nib & 2u) << 7) | ((nib & 4u) << 14) | ((nib & 8u) << 21);
+    }
+    return *reinterpret_cast<const unsigned *>(sp.ref + frame * sp.ref_stride + qd * 4) & 0x01010101u;
+}
 
 // Per-lane partial counters of a fused launch; summed over the workgroup and added to the
 // counters in device memory once, when the workgroup has run out of frames.
@@ -131,8 +145,7 @@ __device__ __forceinline__ void sweep_stage_wave(const SweepDev &sp, float *stag
         const int f = F == 1 ? 0 : i / QUADS, qd = i - f * QUADS;
         long long frame = grp * F + f;
         if (frame >= frames) frame = frames - 1;  // idle slot: any frame that exists
-        unsigned bits = 0;
-        if (sp.ref) bits = *reinterpret_cast<const unsigned *>(sp.ref + frame * sp.ref_stride + qd * 4) & 0x01010101u;
+        const unsigned bits = sweep_ref_quad(sp, frame, qd);
         float v[4];
         channel_quad(sp.ch, sp.ch.first_frame + (unsigned long long)frame, qd, bits, v);
         *reinterpret_cast<float4 *>(stage + f * N + qd * 4) = make_float4(v[0], v[1], v[2], v[3]);
@@ -141,15 +154,22 @@ __device__ __forceinline__ void sweep_stage_wave(const SweepDev &sp, float *stag
 }
 
 // Multi-wave workgroups: the channel LLRs of the F frames of group `grp` into the workgroup's own slice
-// of a scratch buffer in device memory ([F][N] floats; reused group after group, i.e. cache-resident),
-// drawn by all threads of the workgroup, four positions per draw.  Ends with the fences and the barrier
-// that make the slice readable by every wave; the caller's previous group must have ended with a barrier.
+// of a scratch buffer in device memory ([F][N] floats, then the frames' transmitted bits as [F][N] bytes;
+// reused group after group), drawn by all threads of the workgroup, four positions per draw.  Ends with
+// the fences and the barrier that make the slice readable by every wave; the caller's previous group must
+// have ended with a barrier.
+template <int N, int F>
+constexpr size_t sweep_slice_bytes() { return (size_t)F * N * 5; }
+template <int N, int F>
+__device__ __forceinline__ const uint8_t *sweep_slice_ref(const float *slice) { return reinterpret_cast<const uint8_t *>(slice + F * N); }
+
 template <int N, int F>
 __device__ __forceinline__ const float *sweep_stage_group(const SweepDev &sp, float *scratch, long long grp, long long frames)
 {
     static_assert(N % 4 == 0, "positions are generated four at a time");
     constexpr int QUADS = N / 4;
-    float *mine = scratch + (size_t)blockIdx.x * (F * N);
+    float *mine = scratch + (size_t)blockIdx.x * (sweep_slice_bytes<N, F>() / 4);
+    uint8_t *mine_ref = reinterpret_cast<uint8_t *>(mine + F * N);
     // four draws per round, their transmitted bits requested together: a workgroup of these kernels has few
     // waves per SIMD, and one load per draw would leave every draw waiting for its own memory round trip
     constexpr int U = 4, TOTAL = F * QUADS;
@@ -164,8 +184,7 @@ __device__ __forceinline__ const float *sweep_stage_group(const SweepDev &sp, fl
             const int f = F == 1 ? 0 : i / QUADS, qd = i - f * QUADS;
             long long frame = grp * F + f;
             if (frame >= frames) frame = frames - 1;  // idle slot: any frame that exists
-            bits[u] = 0;
-            if (sp.ref) bits[u] = *reinterpret_cast<const unsigned *>(sp.ref + frame * sp.ref_stride + qd * 4) & 0x01010101u;
+            bits[u] = sweep_ref_quad(sp, frame, qd);
             af[u] = sp.ch.first_frame + (unsigned long long)frame;
             at[u] = f * N + qd * 4;
             qds[u] = qd;
@@ -176,6 +195,7 @@ __device__ __forceinline__ const float *sweep_stage_group(const SweepDev &sp, fl
                 float v[4];
                 channel_quad(sp.ch, af[u], qds[u], bits[u], v);
                 *reinterpret_cast<float4 *>(mine + at[u]) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<unsigned *>(mine_ref + at[u]) = bits[u];
             }
         }
     }

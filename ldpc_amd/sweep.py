@@ -204,11 +204,13 @@ def count_errors(dec: Decoder, batch: DeviceBatch, stream: Optional[int] = None)
 
 def sweep_fused(dec: Decoder, cw, snr_db: float, cfg: DecodeConfig, seed, counters, compute_dtype=np.float64,
                 first_frame: int = 0, llr_scale_snr_db: Optional[float] = None, cfo: float = 0.0, phase0: float = 0.0,
-                compat_prefix: bool = False, stream: Optional[int] = None) -> str:
+                compat_prefix: bool = False, stream: Optional[int] = None, packed_n: Optional[int] = None) -> str:
     """Channel, decode and error accounting of the codewords ``cw`` ([frames, n] uint8 on the device,
     as ``make_codewords`` gives them) in one launch
     (``ldpc_sweep_batch``): adds to ``counters`` exactly what ``noisy_batch`` + ``decode_batch`` +
     ``count_errors`` add for the same arguments, without LLRs or hard decisions in device memory.
+    ``packed_n``: ``cw`` holds bits instead ([frames, bytes per word] from ``pack_bits``, words of
+    ``packed_n`` positions; ``ldpc_sweep_batch_packed``).
     Raises ``LdpcError`` (LDPC_ERR_UNSUPPORTED) when no fused kernel serves the code and rule."""
     import ctypes
 
@@ -225,10 +227,30 @@ def sweep_fused(dec: Decoder, cw, snr_db: float, cfg: DecodeConfig, seed, counte
                              int(cfg.plus_is_bit == 1), plen)
     ccfg = CDecodeConfig.from_config(cfg)
     frames, n = cw.shape
-    _lib.check(_lib.load().ldpc_sweep_batch(dec._h, ctypes.byref(ccfg), ctypes.byref(ch), cw.data_ptr(), n, frames,
-                                            _dtype_code(compute_dtype), counters.data_ptr(),
-                                            stream or None))
+    if packed_n is not None:
+        if packed_n != dec.code.n or n < (packed_n + 7) // 8:
+            raise ValueError("packed words do not match the code length")
+        call = _lib.load().ldpc_sweep_batch_packed
+    else:
+        call = _lib.load().ldpc_sweep_batch
+    _lib.check(call(dec._h, ctypes.byref(ccfg), ctypes.byref(ch), cw.data_ptr(), n, frames,
+                    _dtype_code(compute_dtype), counters.data_ptr(), stream or None))
     return _lib.last_kernel()
+
+
+def pack_bits(cw, stream: Optional[int] = None):
+    """Codewords of one byte per bit ([frames, n] uint8 on the device) as bits, eight positions per byte,
+    lowest bit first ([frames, (n + 7) // 8] uint8): the reference words of ``sweep_fused(packed_n=n)``."""
+    import torch
+
+    from . import _lib
+
+    if stream is None:
+        stream = torch.cuda.current_stream().cuda_stream
+    frames, n = cw.shape
+    out = torch.empty((frames, (n + 7) // 8), dtype=torch.uint8, device=cw.device)
+    _lib.check(_lib.load().ldpc_pack_bits(cw.data_ptr(), n, frames, n, out.data_ptr(), out.shape[1], stream or None))
+    return out
 
 
 def allreduce_counters(counters: "torch.Tensor") -> "torch.Tensor":

@@ -87,6 +87,57 @@ def test_fused_half_precision_layered_counters_equal_three_launches(name, snr, f
             assert 0 < fused[1] < frames, fused
 
 
+@pytest.mark.parametrize("name,rule,dtype,snr,frames", [
+    ("ccsds512", "R0", np.float64, 0.5, 20_001), ("ccsds512", "R1", np.float16, -0.75, 20_001),
+    ("wifi648", "R1", np.float32, -1.0, 10_001), ("nr_bg2_z40", "R1", np.float64, -5.5, 3_001),
+    ("nr_bg2_z40", "R1", np.float32, -5.5, 3_001), ("nr_bg2_z40", "R0", np.float64, -2.0, 2_001),
+    ("nr_bg1_z384", "LNMS", np.float32, -3.75, 515), ("nr_bg1_z384", "LNMS", np.float16, -3.75, 515),
+    ("wifi648", "LNMS", np.float64, -1.0, 5_001)])
+def test_fused_with_packed_reference_words(name, rule, dtype, snr, frames):
+    """Transmitted words as bits (ldpc_sweep_batch_packed, n / 8 bytes per frame): the counters of the
+    byte-per-bit call on the same words, through every kind of fused kernel; and one packed word for all
+    frames against the same word repeated."""
+    import torch
+    from ldpc_amd import sweep
+    from ldpc_amd.decoder import Decoder
+    dev = torch.device("cuda", 0)
+    code = codes.load_packaged(name)
+    G = codes.load_packaged_generator(name) if name in ("ccsds512", "wifi648", "nr_bg1_z384") else None
+    dec = Decoder(code)
+    cfg = config.PRESETS[rule]
+    cw = sweep.make_codewords(code, G, frames, [51], dev)
+    bits = sweep.pack_bits(cw)
+    assert bits.shape == (frames, (code.n + 7) // 8)
+    want = np.packbits(cw[:64].cpu().numpy(), axis=1, bitorder="little")
+    assert np.array_equal(bits[:64].cpu().numpy(), want)
+    a = torch.zeros((5,), dtype=torch.int64, device=dev)
+    b = torch.zeros((5,), dtype=torch.int64, device=dev)
+    ka = sweep.sweep_fused(dec, cw, snr, cfg, [52], a, compute_dtype=dtype, first_frame=3)
+    kb = sweep.sweep_fused(dec, bits, snr, cfg, [52], b, compute_dtype=dtype, first_frame=3, packed_n=code.n)
+    torch.cuda.synchronize()
+    assert ka == kb and ka.startswith("fused_spec_")
+    assert a.cpu().numpy().tolist() == b.cpu().numpy().tolist() and a[0] == frames and 0 < a[1] <= frames, (a, b)   # (R0 never converges on the 5G matrix)
+    # one word for all frames: stride 0
+    one = cw[:1].contiguous()
+    rep = one.expand(1000, code.n).contiguous()
+    c = torch.zeros((5,), dtype=torch.int64, device=dev)
+    d = torch.zeros((5,), dtype=torch.int64, device=dev)
+    sweep.sweep_fused(dec, rep, snr, cfg, [53], c, compute_dtype=dtype)
+    import ctypes
+    from ldpc_amd import channel
+    from ldpc_amd.config import CDecodeConfig
+    sigma2, gain, plen, pval = channel.channel_parameters(snr, cfg)
+    key = int(np.random.SeedSequence([53]).generate_state(1, dtype=np.uint64)[0])
+    ch = _lib.CChannelConfig(sigma2, gain, pval, 0.0, 0.0, key, 0, int(cfg.plus_is_bit == 1), plen)
+    ccfg = CDecodeConfig.from_config(cfg)
+    onebits = sweep.pack_bits(one)
+    _lib.check(_lib.load().ldpc_sweep_batch_packed(dec._h, ctypes.byref(ccfg), ctypes.byref(ch), onebits.data_ptr(), 0, 1000,
+                                                   {np.float64: 1, np.float32: 0, np.float16: 2}[dtype], d.data_ptr(),
+                                                   torch.cuda.current_stream().cuda_stream or None))
+    torch.cuda.synchronize()
+    assert c.cpu().numpy().tolist() == d.cpu().numpy().tolist() and c[0] == 1000
+
+
 def test_fused_with_prefix_doppler_and_all_zero_word():
     import torch
     from ldpc_amd import channel, sweep
