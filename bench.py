@@ -78,14 +78,14 @@ def _profile_record(kind, key, fixed, kernel):
     return best
 
 
-def rooflines(code, cfg, dtype, frames, kernel_ms, executed, kernel, code_name, rule_name, fused=False):
+def rooflines(code, cfg, dtype, frames, kernel_ms, executed, kernel, code_name, rule_name, fused=False, packed=False):
     """HBM, LDS and vector-issue rooflines of one launch."""
     itemsize = {"f64": 8, "f32": 4, "f16": 2}[dtype]
-    key = f"{code_name}/{rule_name}/{dtype}/" + ("fused" if fused else "f32llr") + ("/graph" if kernel.startswith("bg_lnms") else "")
+    key = f"{code_name}/{rule_name}/{dtype}/" + (("fused_packed" if packed else "fused") if fused else "f32llr") + ("/graph" if kernel.startswith("bg_lnms") else "")
     fixed = not cfg.early_exit
     sec = kernel_ms * 1e-3
     # decode: f32 LLR in, u8 hard + i32 + u8 out; fused sweep: the transmitted codeword (u8) in, nothing out
-    per_frame = code.n if fused else 5 * code.n + 5
+    per_frame = ((code.n + 7) // 8 if packed else code.n) if fused else 5 * code.n + 5
     hbm_bytes = per_frame * frames
     tr = _profile_record("hbm_traffic", key, fixed, kernel)
     roof = {"bound": "hbm", "achieved": hbm_bytes / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -168,7 +168,7 @@ class Runner:
         self.dec = Decoder(self.code)
 
     def run(self, rule, dtype, snr, early, frames, steps, warmup, max_iters=10, seed=7, kernel=0, with_rooflines=False,
-            fused=False):
+            fused=False, packed=False):
         """`fused`: a step is channel + decode + error accounting in one launch (ldpc_sweep_batch) on
         codewords resident in HBM, instead of the decode of LLRs resident in HBM."""
         from ldpc_amd import config, sweep
@@ -176,10 +176,12 @@ class Runner:
         batch = sweep.make_batch(self.code, self.G, frames, snr, cfg, seed=[seed, self.rank], device=self.device)
         compute = {"f64": np.float64, "f32": np.float32, "f16": np.float16}[dtype]
         kname = [""]
+        ref_words = sweep.pack_bits(batch.ref) if fused and packed else batch.ref   # transmitted words as bits: n / 8 bytes per frame
 
         def step():
             if fused:
-                kname[0] = sweep.sweep_fused(self.dec, batch.ref, snr, cfg, [seed, self.rank], batch.counters, compute_dtype=compute)
+                kname[0] = sweep.sweep_fused(self.dec, ref_words, snr, cfg, [seed, self.rank], batch.counters, compute_dtype=compute,
+                                             packed_n=self.code.n if packed else None)
             else:
                 kname[0] = sweep.decode_batch(self.dec, batch, cfg, compute_dtype=compute, kernel=kernel)
 
@@ -201,7 +203,7 @@ class Runner:
         if with_rooflines:
             # iterations actually run: failures ran max_iters but report max-1; fixed mode reports max_iters
             executed = (st["iterations"] + (st["not_converged"] if early else 0)) / self.world
-            res.update(rooflines(self.code, cfg, dtype, frames, dev_ms / steps, executed, kname[0], self.name, rule, fused))
+            res.update(rooflines(self.code, cfg, dtype, frames, dev_ms / steps, executed, kname[0], self.name, rule, fused, packed))
         return res, batch, cfg
 
 
@@ -288,6 +290,7 @@ def main():
                     "iteration instead of exactly max-iters updates per frame")
     ap.add_argument("--fixed", action="store_true", help="(default) exactly max-iters updates per frame")
     ap.add_argument("--cpu-sample", type=int, default=0, help="frames of the CPU baseline (0 = auto)")
+    ap.add_argument("--packed-ref", action="store_true", help="with --fused: the transmitted codewords as bits (n / 8 bytes per frame)")
     ap.add_argument("--fused", action="store_true", help="a step is channel + decode + error accounting in one launch "
                     "(ldpc_sweep_batch) instead of the decode alone")
     ap.add_argument("--no-cpu", action="store_true")
@@ -325,7 +328,7 @@ def main():
         args.frames = 1 << 20 if code.n <= 1024 else 16384
     early = bool(args.early_exit)
     res, batch, cfg = head.run(args.rule, args.dtype, args.snr, early, args.frames, args.steps, args.warmup,
-                               max_iters=args.max_iters, kernel=args.kernel, with_rooflines=True, fused=args.fused)
+                               max_iters=args.max_iters, kernel=args.kernel, with_rooflines=True, fused=args.fused, packed=args.packed_ref)
     rule_text = {'R0': 'ldpc.py decoder', 'R1': 'bpsk.py decoder', 'LNMS': 'layered min-sum, build extension'}.get(args.rule, 'sum-product')
     out = {
         "metric": "decoded info Gbit/s", "value": res["value"], "unit": "Gbit/s", "n_gpus": world,

@@ -26,6 +26,7 @@ BENCH_PATH = {
     "ccsds512/R0/f64/f32llr": ("value",),
     "ccsds512/R0/f64/f32llr/early_exit": ("operating_point", "value"),
     "ccsds512/R0/f64/fused": ("other", "sweep_R0_f64_es_n0_1dB", "fused_gbit_s"),
+    "ccsds512/R0/f64/fused_packed": None,
     "nr_bg1_z384/LNMS/f32/f32llr": ("bg1", "f32", "value"),
     "nr_bg1_z384/LNMS/f64/f32llr": ("bg1", "f64", "value"),
     "nr_bg1_z384/LNMS/f16/f32llr": ("bg1", "f16x2", "value"),
@@ -67,6 +68,8 @@ def main():
         mode = "early exit" if s["early_exit"] else "10 fixed"
         if key.endswith("/fused"):
             mode = "fused sweep, early exit"
+        if key.endswith("/fused_packed"):
+            mode = "fused sweep, packed reference words, early exit"
         l, h = lds.get(key), hbm.get(key)
         ms = l["kernel_ms"] if l else None
         rate = dig(bench, BENCH_PATH[key]) if bench and BENCH_PATH.get(key) else None

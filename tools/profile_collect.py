@@ -16,7 +16,7 @@ from ldpc_amd.build import kernel_source_digest  # noqa: E402
 tag = sys.argv[1]
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(ROOT, "profiles")
-WORKLOADS = {"ccsds_r0_f64": "ccsds512/R0/f64/f32llr", "ccsds_r0_f64_fused": "ccsds512/R0/f64/fused",
+WORKLOADS = {"ccsds_r0_f64": "ccsds512/R0/f64/f32llr", "ccsds_r0_f64_fused": "ccsds512/R0/f64/fused", "ccsds_r0_f64_fused_packed": "ccsds512/R0/f64/fused_packed",
              "ccsds_r0_f64_ee": "ccsds512/R0/f64/f32llr/early_exit", "bg1_lnms_f32": "nr_bg1_z384/LNMS/f32/f32llr",
              "bg1_lnms_f64": "nr_bg1_z384/LNMS/f64/f32llr", "bg1_lnms_f16": "nr_bg1_z384/LNMS/f16/f32llr",
              "bg1_bglnms_f32": "nr_bg1_z384/LNMS/f32/f32llr/graph", "bg1_bglnms_f64": "nr_bg1_z384/LNMS/f64/f32llr/graph",
