@@ -138,6 +138,28 @@ def test_fused_with_packed_reference_words(name, rule, dtype, snr, frames):
     assert c.cpu().numpy().tolist() == d.cpu().numpy().tolist() and c[0] == 1000
 
 
+def test_pack_bits_ragged_word_length():
+    """Words whose length is not a multiple of eight, bytes whose upper bits are set: the low bit counts,
+    the unused bits of the last byte are zero."""
+    import ctypes
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(3)
+    for frames, n in ((1, 1), (5, 13), (300, 1001)):
+        raw = rng.integers(0, 256, size=(frames, n + 3), dtype=np.uint8)      # rows 3 bytes apart from dense
+        src = torch.as_tensor(raw, device=dev)
+        out = torch.full((frames, (n + 7) // 8 + 2), 0xAA, dtype=torch.uint8, device=dev)
+        _lib.check(_lib.load().ldpc_pack_bits(src.data_ptr(), n + 3, frames, n, out.data_ptr(), out.shape[1],
+                                              torch.cuda.current_stream().cuda_stream or None))
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()
+        want = np.packbits(raw[:, :n] & 1, axis=1, bitorder="little")
+        assert np.array_equal(got[:, :want.shape[1]], want)
+        assert (got[:, want.shape[1]:] == 0xAA).all()                            # nothing written beyond a word
+    with pytest.raises(_lib.LdpcError):
+        _lib.check(_lib.load().ldpc_pack_bits(src.data_ptr(), 5, 2, 8, out.data_ptr(), 1, None))   # stride shorter than a word
+
+
 def test_fused_with_prefix_doppler_and_all_zero_word():
     import torch
     from ldpc_amd import channel, sweep
