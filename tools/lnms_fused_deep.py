@@ -16,7 +16,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from ldpc_amd import codes, config, sweep  # noqa: E402
+from ldpc_amd import codes, config, encoder, sweep  # noqa: E402
 from ldpc_amd.decoder import Decoder  # noqa: E402
 
 
@@ -25,7 +25,7 @@ def main():
     out_name = sys.argv[1]
     points = [(int(a.split("@")[0]), float(a.split("@")[1])) for a in sys.argv[2:]]
     code = codes.load_packaged("nr_bg1_z384")
-    G = codes.load_packaged_generator("nr_bg1_z384")
+    G = encoder.device_encoder(code, None)   # messages drawn and encoded on the device
     dec = Decoder(code)
     cfg = config.LNMS.with_(max_iters=10, early_exit=True)
     chunk = 1 << 15
