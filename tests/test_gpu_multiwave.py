@@ -32,7 +32,7 @@ def noisy_llrs(name, cfg, B, snr, seed):
 
 
 EXPECT = [  # code, rule, kernel that must serve it in double
-    ("wifi648", "R0", "spec_r0w_f64"), ("wifi648", "R1", "spec_r1w_f64"), ("wifi648", "R3", "spec_spaw_f64"),
+    ("wifi648", "R0", "spec_r0w_f64"), ("wifi648", "R1", "spec_r1m_f64"), ("wifi648", "R3", "spec_spaw_f64"),
     ("nr_bg2_z40", "R0", "spec_r0w_f64"), ("nr_bg2_z40", "R1", "spec_r1m_f64"),
     ("nr_bg2_z40", "R2", "spec_spaw_f64"), ("nr_bg2_z40", "R3", "spec_spaw_f64"), ("nr_bg2_z40", "R4", "spec_spaw_f64"),
     ("nr_bg2_z40_r1400", "R0", "spec_r0w_f64"), ("nr_bg2_z40_r1400", "R1", "spec_r1m_f64"),

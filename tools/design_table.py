@@ -35,6 +35,7 @@ BENCH_PATH = {
     "ccsds512/R3/f32/f32llr": ("other", "R3_f32_fixed_10", "gbit_s"),
     "ccsds512/R3/f64/f32llr": ("other", "R3_f64_fixed_10", "gbit_s"),
     "ccsds512/R1/f64/f32llr": ("other", "R1_f64_fixed_10", "gbit_s"),
+    "wifi648/R1/f64/f32llr": ("other", "WIFI648_R1_f64_fixed_10", "gbit_s"),
     "nr_bg2_z40/R0/f64/f32llr": ("other", "BG2_Z40_R0_f64_fixed_10", "gbit_s"),
     "nr_bg2_z40/R0/f32/f32llr": ("other", "BG2_Z40_R0_f32_fixed_10", "gbit_s"),
     "nr_bg2_z40/R1/f64/f32llr": ("other", "BG2_Z40_R1_f64_fixed_10", "gbit_s"),

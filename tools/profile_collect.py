@@ -20,7 +20,7 @@ WORKLOADS = {"ccsds_r0_f64": "ccsds512/R0/f64/f32llr", "ccsds_r0_f64_fused": "cc
              "ccsds_r0_f64_ee": "ccsds512/R0/f64/f32llr/early_exit", "bg1_lnms_f32": "nr_bg1_z384/LNMS/f32/f32llr",
              "bg1_lnms_f64": "nr_bg1_z384/LNMS/f64/f32llr", "bg1_lnms_f16": "nr_bg1_z384/LNMS/f16/f32llr",
              "bg1_bglnms_f32": "nr_bg1_z384/LNMS/f32/f32llr/graph", "bg1_bglnms_f64": "nr_bg1_z384/LNMS/f64/f32llr/graph",
-             "ccsds_R3_f32": "ccsds512/R3/f32/f32llr", "ccsds_R3_f64": "ccsds512/R3/f64/f32llr", "ccsds_R1_f64": "ccsds512/R1/f64/f32llr",
+             "ccsds_R3_f32": "ccsds512/R3/f32/f32llr", "ccsds_R3_f64": "ccsds512/R3/f64/f32llr", "ccsds_R1_f64": "ccsds512/R1/f64/f32llr", "wifi_R1_f64": "wifi648/R1/f64/f32llr",
              "bg2_R0_f64": "nr_bg2_z40/R0/f64/f32llr", "bg2_R0_f32": "nr_bg2_z40/R0/f32/f32llr",
              "bg2_R1_f64": "nr_bg2_z40/R1/f64/f32llr", "bg2r1400_R1_f64": "nr_bg2_z40_r1400/R1/f64/f32llr", "bg2_R1_f32": "nr_bg2_z40/R1/f32/f32llr",
              "bg2_R3_f32": "nr_bg2_z40/R3/f32/f32llr", "bg2_R3_f64": "nr_bg2_z40/R3/f64/f32llr"}

@@ -27,10 +27,11 @@ W[bg2_R0_f64]="--code nr_bg2_z40 --frames 32768 --snr -2.0 --rule R0 --dtype f64
 W[bg2_R0_f32]="--code nr_bg2_z40 --frames 32768 --snr -2.0 --rule R0 --dtype f32"
 W[bg2_R1_f64]="--code nr_bg2_z40 --frames 32768 --snr -2.0 --rule R1 --dtype f64"
 W[bg2r1400_R1_f64]="--code nr_bg2_z40_r1400 --frames 32768 --snr -2.0 --rule R1 --dtype f64"
+W[wifi_R1_f64]="--code wifi648 --frames 65536 --rule R1 --dtype f64"
 W[bg2_R1_f32]="--code nr_bg2_z40 --frames 32768 --snr -2.0 --rule R1 --dtype f32"
 W[bg2_R3_f32]="--code nr_bg2_z40 --frames 32768 --snr -2.0 --rule R3 --dtype f32"
 W[bg2_R3_f64]="--code nr_bg2_z40 --frames 8192 --snr -2.0 --rule R3 --dtype f64"
-LIST=${@:-ccsds_r0_f64 ccsds_r0_f64_fused ccsds_r0_f64_fused_packed ccsds_r0_f64_ee ccsds_R1_f64 bg1_lnms_f32 bg1_lnms_f64 bg1_lnms_f16 bg1_bglnms_f32 ccsds_R3_f32 ccsds_R3_f64 bg2_R0_f64 bg2_R1_f64 bg2r1400_R1_f64 bg2_R1_f32 bg2_R3_f32}
+LIST=${@:-ccsds_r0_f64 ccsds_r0_f64_fused ccsds_r0_f64_fused_packed ccsds_r0_f64_ee ccsds_R1_f64 wifi_R1_f64 bg1_lnms_f32 bg1_lnms_f64 bg1_lnms_f16 bg1_bglnms_f32 ccsds_R3_f32 ccsds_R3_f64 bg2_R0_f64 bg2_R1_f64 bg2r1400_R1_f64 bg2_R1_f32 bg2_R3_f32}
 SQ="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_ANY"
 LDS="SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_LDS_LOAD SQ_INSTS_LDS_STORE SQ_BUSY_CU_CYCLES SQ_WAIT_INST_LDS"
 for name in $LIST; do
