@@ -477,23 +477,27 @@ def link_workloads(head, bg2, args, torch, dist, device, world, rank):
     channel (BASELINE configuration 5), the device encoder and 5G rate recovery."""
     from ldpc_amd import channel, config, encoder, nr_rate_match, sweep
     res = {}
-    for label, rn, rule, dtype, snr, frames in (
-            ("sweep_R0_f64_es_n0_1dB", head, "R0", np.float64, 1.0, min(args.frames, 1 << 19)),
-            ("sweep_R1_f32_es_n0_1dB", head, "R1", np.float32, 1.0, min(args.frames, 1 << 19)),
-            ("sweep_R1_f16x2_es_n0_1dB", head, "R1", np.float16, 1.0, min(args.frames, 1 << 19)),   # packed half precision: reduced precision
+    cfo5 = channel.doppler_cfo(4000.0, compensated=0.999)   # the carrier offset of configuration 5
+    for label, rn, rule, dtype, snr, frames, chan in (
+            ("sweep_R0_f64_es_n0_1dB", head, "R0", np.float64, 1.0, min(args.frames, 1 << 19), {}),
+            ("sweep_R1_f32_es_n0_1dB", head, "R1", np.float32, 1.0, min(args.frames, 1 << 19), {}),
+            ("sweep_R1_f16x2_es_n0_1dB", head, "R1", np.float16, 1.0, min(args.frames, 1 << 19), {}),   # packed half precision: reduced precision
             # the large codes stage their LLRs in a scratch slice per workgroup: the fused launch saves the LLR
             # array and its HBM traffic, not time - channel and decode are bound by vector issue alike
-            ("sweep_BG2_Z40_R1_f64_es_n0_-4dB", bg2, "R1", np.float64, -4.0, 32768)):
+            ("sweep_BG2_Z40_R1_f64_es_n0_-4dB", bg2, "R1", np.float64, -4.0, 32768, {}),
+            # the two halves of configuration 5 as whole Monte-Carlo steps: sum-product rule R3 under the Doppler-shifted channel
+            ("sweep_R3_f32_doppler_es_n0_1dB", head, "R3", np.float32, 1.0, min(args.frames, 1 << 18), {"cfo": cfo5}),
+            ("sweep_BG2_Z40_R3_f32_doppler_es_n0_-4dB", bg2, "R3", np.float32, -4.0, 16384, {"cfo": cfo5})):
         code, dec = rn.code, rn.dec
         cfg = config.PRESETS[rule].with_(max_iters=args.max_iters)
         cw = sweep.make_codewords(code, rn.G, frames, [31, rank], device)
         ctr = torch.zeros((5,), dtype=torch.int64, device=device)
 
         def fused():
-            sweep.sweep_fused(dec, cw, snr, cfg, [32, rank], ctr, compute_dtype=dtype)
+            sweep.sweep_fused(dec, cw, snr, cfg, [32, rank], ctr, compute_dtype=dtype, **chan)
 
         def three():
-            bt = sweep.noisy_batch(code, cw, snr, cfg, [32, rank], device)
+            bt = sweep.noisy_batch(code, cw, snr, cfg, [32, rank], device, **chan)
             sweep.decode_batch(dec, bt, cfg, compute_dtype=dtype)
             sweep.count_errors(dec, bt)
 
@@ -505,7 +509,7 @@ def link_workloads(head, bg2, args, torch, dist, device, world, rank):
         del cw
     # configuration 5: CCSDS and 5G frames of one link in one call, sum-product rule R3, Doppler-shifted BPSK
     cfg = config.R3.with_(max_iters=args.max_iters)
-    cfo = channel.doppler_cfo(4000.0, compensated=0.999)
+    cfo = cfo5
     parts = []
     for runner, fr, snr in ((head, 1 << 16, 1.0), (bg2, 1 << 13, -4.0)):
         cwp = sweep.make_codewords(runner.code, runner.G, fr, [33, rank], device)

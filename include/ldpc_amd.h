@@ -355,9 +355,10 @@ int32_t ldpc_rate_recover(const ldpc_rate_match_config *cfg, const void *llr_dev
  * ldpc_count_errors: the five numbers added to counters_dev equal, bit for bit, what the three
  * calls in a row add for the same arguments.  ref_dev: transmitted codewords [frames, n]
  * (ref_stride = n), one codeword for all frames (ref_stride = 0) or NULL (the all-zero codeword);
- * 4-byte aligned.  Served for the compiled-in codes (rules R0, R1, OMS and LNMS in LDPC_F32 / LDPC_F64;
- * rule R1 on the small ones and LNMS in LDPC_F16); LDPC_ERR_UNSUPPORTED otherwise (sum-product rules,
- * matrices that are not compiled in, loop-bound quirks), and the three calls are the fallback.
+ * 4-byte aligned.  Served for the compiled-in codes (rules R0, R1, OMS, LNMS and the sum-product rules
+ * R2, R3, R4 with their posterior clip in LDPC_F32 / LDPC_F64; rule R1 on the small codes and LNMS in
+ * LDPC_F16); LDPC_ERR_UNSUPPORTED otherwise (matrices that are not compiled in, loop-bound quirks, a
+ * posterior clip under a min-sum rule), and the three calls are the fallback.
  */
 typedef struct ldpc_channel_config {
     double sigma2;                 /* noise variance, 1 / (2 * 10^(SNR/10)), ldpc.py:245 */

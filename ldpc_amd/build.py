@@ -26,7 +26,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 #: (object name, source, extra flags)
 # slowest units first: the pool starts them in this order
 UNITS = [(f"decode_spec_spaw_r{k}.o", "decode_spec_spaw.hip", [f"-DLDPC_SPAW_RULE={k}"]) for k in (2, 3, 4)]
+UNITS += [(f"decode_spec_spaw_fused_r{k}.o", "decode_spec_spaw.hip", [f"-DLDPC_SPAW_RULE={k}", "-DLDPC_SPEC_FUSED"]) for k in (2, 3, 4)]
 UNITS += [("decode_spec_spa.o", "decode_spec_spa.hip", []),
+          ("decode_spec_spa_fused.o", "decode_spec_spa.hip", ["-DLDPC_SPEC_FUSED"]),
           ("decode_lnms.o", "decode_lnms.hip", []),
           ("decode_lnms_rt_bg1.o", "decode_lnms_rt.hip", ["-DLDPC_BG_GRAPH=0"]),
           ("decode_lnms_rt_bg2.o", "decode_lnms_rt.hip", ["-DLDPC_BG_GRAPH=1"]),

@@ -16,7 +16,13 @@
 // R4  channel.py:260-398  phi rule, sum clip [1e-12, 20], posterior clip 500
 // The clips arrive in the configuration; prefix products and suffix products replace the
 // reference's per-target loops (agreement to rounding, see the table-driven kernel).
+//
+// FUSED: the channel in front and the error accounting behind run inside the kernel (sweep_fused.h),
+// as in the single-wave min-sum kernels of decode_spec.hip: the lanes draw the LLRs of the group's
+// frames into an LDS staging area, the frames' transmitted bits beside them, and a frame that ends
+// books its bit errors and flags instead of writing results.  llr and the result arrays are unused.
 #include "spec_common.h"
+#include "sweep_fused.h"
 
 namespace ldpc {
 
@@ -45,10 +51,10 @@ struct SpaLayout {
     static constexpr int LDS_BYTES = F * SLOT_BYTES;
 };
 
-template <int RULE, class C, typename T, typename TL, int F>
+template <int RULE, class C, typename T, typename TL, int F, bool FUSED = false>
 __global__ void __launch_bounds__(64)
 spec_spa_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__restrict__ hard_out,
-                int *__restrict__ iters_out, uint8_t *__restrict__ conv_out, T *__restrict__ post_out)
+                int *__restrict__ iters_out, uint8_t *__restrict__ conv_out, T *__restrict__ post_out, SweepDev sp)
 {
     typedef SpaLayout<C, T, F> LY;
     static_assert(LY::THREADS == 64, "single-wave workgroups only");
@@ -64,8 +70,11 @@ spec_spa_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t 
     const unsigned zb = (unsigned)z * ST;
     const unsigned long long slot_mask = (Z >= 64 ? ~0ull : ((1ull << (Z & 63)) - 1ull)) << ((f * Z) & 63);
 
-    constexpr bool PREFETCH = llr_prefetch_pays<C, TL>(LY::LDS_BYTES);  // see llr_prefetch
+    constexpr bool PREFETCH = !FUSED && llr_prefetch_pays<C, TL>(LY::LDS_BYTES);  // see llr_prefetch
     __shared__ float stage[PREFETCH ? NB * 64 : 1];  // [NB][lane]
+    __shared__ __align__(16) float fstage[FUSED ? F * n : 1];  // fused: channel LLRs by position
+    __shared__ __align__(4) uint8_t fref[FUSED ? F * n : 4];   //        and the transmitted bits
+    SweepAcc acc;
     const long long groups = (frames + F - 1) / F;
     if constexpr (PREFETCH) {
         if (blockIdx.x < groups) llr_prefetch<C, F>(stage, llr, blockIdx.x, frames, lane_on, f, z);
@@ -77,10 +86,15 @@ spec_spa_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t 
         T ml[LY::NLOCAL > 0 ? LY::NLOCAL : 1];  // messages of the lane-local edges
         unsigned long long hm[NB];
         if constexpr (PREFETCH) __builtin_amdgcn_s_waitcnt(0);  // the staged LLRs have landed
+        if constexpr (FUSED) {  // one wave: its LDS operations execute in order, no barrier needed
+            sweep_stage_wave<n, F>(sp, fstage, fref, grp, frames, tid);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
         static_for<0, NB>([&](auto bc) {
             constexpr int k0 = C::col_ptr[bc], D = C::col_ptr[bc + 1] - k0;
             T l;
-            if constexpr (PREFETCH) l = active ? (T)stage[bc * 64 + tid] : (T)0;
+            if constexpr (FUSED) l = active ? (T)fstage[f * n + bc * Z + z] : (T)0;
+            else if constexpr (PREFETCH) l = active ? (T)stage[bc * 64 + tid] : (T)0;
             else l = active ? (T)llr[frame * n + bc * Z + z] : (T)0;
             L[bc] = l;
             own[bc] = l;
@@ -96,12 +110,19 @@ spec_spa_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t 
             if (grp + gridDim.x < groups) llr_prefetch<C, F>(stage, llr, grp + gridDim.x, frames, lane_on, f, z);
         }
 
+        // results of a frame: to the arrays, or (fused) into the error counters
         auto write_out = [&](int iters, int conv) {
+            unsigned errs = 0;
             static_for<0, NB>([&](auto bc) {
-                hard_out[frame * n + bc * Z + z] = (uint8_t)hard_bit<RULE>(own[bc]);
-                if (post_out) post_out[frame * n + bc * Z + z] = own[bc];
+                const uint8_t hv = (uint8_t)hard_bit<RULE>(own[bc]);
+                if constexpr (FUSED) errs += hv != fref[f * n + bc * Z + z];
+                else {
+                    hard_out[frame * n + bc * Z + z] = hv;
+                    if (post_out) post_out[frame * n + bc * Z + z] = own[bc];
+                }
             });
-            if (z == 0) { iters_out[frame] = iters; conv_out[frame] = (uint8_t)conv; }
+            if constexpr (FUSED) acc.book(errs, (__ballot(errs != 0) & slot_mask) != 0ull, z == 0, iters, conv);
+            else if (z == 0) { iters_out[frame] = iters; conv_out[frame] = (uint8_t)conv; }
         };
 
         bool done = !active;
@@ -203,15 +224,24 @@ spec_spa_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t 
             else write_out(g.max_iters, r1_slot_ok<C, F>(hm, slot_mask) ? 1 : 0);
         }
     }
+    if constexpr (FUSED) acc.flush_wave(sp.counters);
 }
 
 // ------------------------------------------------------------------------------------------ host
 // One wave per workgroup: with fewer than eight resident workgroups per compute unit (LDS or
 // registers) the long dependent chains of the transcendentals are not hidden and the table-driven
 // kernel, which spreads a frame over several waves, is faster; *supported = false sends the call there.
+// This file is compiled twice, like decode_spec.hip: as it is (the decoders behind ldpc_decode_batch) and
+// with -DLDPC_SPEC_FUSED (the fused variants behind ldpc_sweep_batch).
+#ifdef LDPC_SPEC_FUSED
+constexpr bool kFused = true;
+#else
+constexpr bool kFused = false;
+#endif
+
 template <int RULE, class C, typename T, typename TL, int F>
 static hipError_t launch_spa(const ldpc_decode_config &cfg, const Launch &io, int num_cus, const char **name,
-                             bool *supported)
+                             bool *supported, const SweepDev *sp)
 {
     typedef SpaLayout<C, T, F> LY;
     Cfg<T> g;
@@ -219,61 +249,84 @@ static hipError_t launch_spa(const ldpc_decode_config &cfg, const Launch &io, in
     g.float_syndrome0 = 0; g.num_active_checks = -1; g.num_refresh_vars = -1;
     g.scale = (T)cfg.scale; g.clip_tanh_arg = (T)cfg.clip_tanh_arg; g.clip_prod = (T)cfg.clip_prod;
     g.clip_post = (T)cfg.clip_post; g.offset = (T)cfg.offset;
-    auto k = spec_spa_kernel<RULE, C, T, TL, F>;
+    auto k = spec_spa_kernel<RULE, C, T, TL, F, kFused>;
     int per_cu = 0;
     hipError_t e = kernel_setup(reinterpret_cast<const void *>(k), 64, LY::LDS_BYTES, &per_cu);
     if (e != hipSuccess) return e;
-    if (per_cu < 8) { *supported = false; return hipSuccess; }
+    // the plain kernel decides which codes this file serves, so that a code's fused sweep runs the kernel
+    // family its three launches run (the fused variant holds F * n * 5 bytes of staging besides)
+    if (kFused ? (160 * 1024) / LY::LDS_BYTES < 8 : per_cu < 8) { *supported = false; return hipSuccess; }
+    if (per_cu < 1) per_cu = 1;
     const long long groups = (io.frames + F - 1) / F;
     long long grid = (long long)num_cus * per_cu * 2;
     if (grid > groups) grid = groups;
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(64), LY::LDS_BYTES, io.stream, g,
                        reinterpret_cast<const TL *>(io.llr), io.frames, io.hard, io.iters, io.converged,
-                       reinterpret_cast<T *>(io.posterior));
-    *name = sizeof(T) == 8 ? "spec_spa_f64" : "spec_spa_f32";
+                       reinterpret_cast<T *>(io.posterior), sp ? *sp : SweepDev{});
+    *name = kFused ? (sizeof(T) == 8 ? "fused_spec_spa_f64" : "fused_spec_spa_f32") : (sizeof(T) == 8 ? "spec_spa_f64" : "spec_spa_f32");
     return hipGetLastError();
 }
 
+// sp != NULL only in the fused build, where the LLRs are floats drawn in the kernel
 template <int RULE, class C, int F>
 static hipError_t launch_spa_rule(const ldpc_decode_config &cfg, int compute_dtype, const Launch &io, int num_cus,
-                                  const char **name, bool *supported)
+                                  const char **name, bool *supported, const SweepDev *sp)
 {
     *supported = true;
     if (compute_dtype == LDPC_F64) {
-        if (io.llr_dtype == LDPC_F64) return launch_spa<RULE, C, double, double, F>(cfg, io, num_cus, name, supported);
-        return launch_spa<RULE, C, double, float, F>(cfg, io, num_cus, name, supported);
+        if constexpr (!kFused) {
+            if (io.llr_dtype == LDPC_F64) return launch_spa<RULE, C, double, double, F>(cfg, io, num_cus, name, supported, sp);
+        }
+        return launch_spa<RULE, C, double, float, F>(cfg, io, num_cus, name, supported, sp);
     }
-    if (io.llr_dtype == LDPC_F32) return launch_spa<RULE, C, float, float, F>(cfg, io, num_cus, name, supported);
+    if (kFused || io.llr_dtype == LDPC_F32) return launch_spa<RULE, C, float, float, F>(cfg, io, num_cus, name, supported, sp);
     *supported = false;
     return hipSuccess;
 }
 
 template <class C, int F>
 static hipError_t launch_spa_code(const ldpc_decode_config &cfg, int compute_dtype, const Launch &io, int num_cus,
-                                  const char **name, bool *supported)
+                                  const char **name, bool *supported, const SweepDev *sp)
 {
     *supported = false;
     // small base graphs only: the whole graph is unrolled
-    if constexpr (C::EB <= 100 && SpaLayout<C, double, F>::THREADS == 64 && SpaLayout<C, double, F>::LDS_BYTES <= 160 * 1024) {
-        if (cfg.rule == 2) return launch_spa_rule<2, C, F>(cfg, compute_dtype, io, num_cus, name, supported);
-        if (cfg.rule == 3) return launch_spa_rule<3, C, F>(cfg, compute_dtype, io, num_cus, name, supported);
-        if (cfg.rule == 4) return launch_spa_rule<4, C, F>(cfg, compute_dtype, io, num_cus, name, supported);
+    if constexpr (C::EB <= 100 && SpaLayout<C, double, F>::THREADS == 64 && SpaLayout<C, double, F>::LDS_BYTES <= 160 * 1024 &&
+                  (!kFused || (C::NB * C::Z) % 4 == 0)) {
+        if (cfg.rule == 2) return launch_spa_rule<2, C, F>(cfg, compute_dtype, io, num_cus, name, supported, sp);
+        if (cfg.rule == 3) return launch_spa_rule<3, C, F>(cfg, compute_dtype, io, num_cus, name, supported, sp);
+        if (cfg.rule == 4) return launch_spa_rule<4, C, F>(cfg, compute_dtype, io, num_cus, name, supported, sp);
     }
     return hipSuccess;
 }
 
-hipError_t launch_spec_spa(int spec_id, const ldpc_decode_config &cfg, int compute_dtype, const Launch &io,
-                           int num_cus, const char **name, bool *supported)
+#ifdef LDPC_SPEC_FUSED
+// Fused sweep on the single-wave sum-product kernels (rules R2, R3, R4 on the small compiled-in codes)
+hipError_t launch_spec_spa_fused(int spec_id, const ldpc_decode_config &cfg, int compute_dtype, const Launch &io,
+                                 const SweepDev &sp, int num_cus, const char **name, bool *supported)
 {
     int id = 0;
 #define LDPC_LAUNCH(CODE, SLOTS)                                                                   \
-    if (spec_id == id) return launch_spa_code<CODE, SLOTS>(cfg, compute_dtype, io, num_cus, name, supported); \
+    if (spec_id == id) return launch_spa_code<CODE, SLOTS>(cfg, compute_dtype, io, num_cus, name, supported, &sp); \
     ++id;
     LDPC_FOR_EACH_SPEC_CODE(LDPC_LAUNCH)
 #undef LDPC_LAUNCH
     *supported = false;
     return hipSuccess;
 }
+#else
+hipError_t launch_spec_spa(int spec_id, const ldpc_decode_config &cfg, int compute_dtype, const Launch &io,
+                           int num_cus, const char **name, bool *supported)
+{
+    int id = 0;
+#define LDPC_LAUNCH(CODE, SLOTS)                                                                   \
+    if (spec_id == id) return launch_spa_code<CODE, SLOTS>(cfg, compute_dtype, io, num_cus, name, supported, nullptr); \
+    ++id;
+    LDPC_FOR_EACH_SPEC_CODE(LDPC_LAUNCH)
+#undef LDPC_LAUNCH
+    *supported = false;
+    return hipSuccess;
+}
+#endif
 
 }  // namespace ldpc

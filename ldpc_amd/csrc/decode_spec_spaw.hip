@@ -12,7 +12,11 @@
 // slots with a zero syndrome stop | check phase | barrier | variable phase | barrier.
 //
 // R2  bpsk.py:263-387     R3  channel.py:402-513     R4  channel.py:260-398
+//
+// Compiled a second time with -DLDPC_SPEC_FUSED for ldpc_sweep_batch: spec_spaw_kernel with the channel
+// in front and the error accounting behind (FUSED, as in spec_r1w_kernel of decode_spec_r1w.hip).
 #include "spec_r1w_plan.h"
+#include "sweep_fused.h"
 
 namespace ldpc {
 
@@ -23,15 +27,20 @@ struct SpawLayout {
     static constexpr int HB_BYTES = ((C::NB * C::Z + 15) / 16) * 16;
     static constexpr int SLOT_BYTES = ((MSG_BYTES + HB_BYTES + 127) / 128) * 128 + (F > 1 ? 32 : 0);
     static constexpr int FLAG_OFF = F * SLOT_BYTES;
-    static constexpr int LDS_BYTES = FLAG_OFF + 64;
+    static constexpr int LDS_BYTES = FLAG_OFF + 96;  // flags: two rows of eight (syndromes), one more for the fused sweep
 };
 
 // REF: variables from g.num_refresh_vars on keep sending their channel value (the reference's refresh
 // loops run over range(self.n), the constructor's n: bpsk.py:356, channel.py:358,480).
-template <int RULE, class C, typename T, typename TL, int F, int W, bool REF = false>
+// FUSED: the workgroup draws the LLRs of its F frames into its own slice of `scratch` ([F][n] floats +
+// [F][n] reference bytes in device memory, reused group after group) and decodes from there; every lane
+// counts the bit errors of the variables it owns against the transmitted word, the per-frame flags meet in
+// LDS.  llr and the result arrays are unused.
+template <int RULE, class C, typename T, typename TL, int F, int W, bool REF = false, bool FUSED = false>
 __global__ void __launch_bounds__(64 * W * ((F * C::Z + 63) / 64))
 spec_spaw_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__restrict__ hard_out,
-                 int *__restrict__ iters_out, uint8_t *__restrict__ conv_out, T *__restrict__ post_out)
+                 int *__restrict__ iters_out, uint8_t *__restrict__ conv_out, T *__restrict__ post_out, SweepDev sp,
+                 float *scratch)
 {
     typedef SpawLayout<C, T, F> LY;
     typedef R1wPlan<C, W> PL;
@@ -49,11 +58,16 @@ spec_spaw_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t
     unsigned char *hb_b = msg_b + LY::MSG_BYTES;       // [NB][Z] u8
     int *flags = reinterpret_cast<int *>(smem + LY::FLAG_OFF);  // [2][8]: failed-syndrome flag per slot, by iteration parity
     const unsigned zb = (unsigned)z * ST, z1 = (unsigned)z;
+    SweepAcc acc;
 
     const long long groups = (frames + F - 1) / F;
     for (long long grp = blockIdx.x; grp < groups; grp += gridDim.x) {
         const long long frame = grp * F + f;
         const bool active = lane_on && frame < frames;
+        const float *mine = nullptr;
+        if constexpr (FUSED) {
+            mine = sweep_stage_group<n, F>(sp, scratch, grp, frames);
+        }
         T L[NBW], own[NBW];
         static_for<0, W>([&](auto w) {
             if (wave == w) {
@@ -61,7 +75,9 @@ spec_spaw_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t
                     if constexpr (j < PL::COLS.cnt[w]) {
                         constexpr int bc = PL::COLS.item[w][j];
                         constexpr int k0 = C::col_ptr[bc], D = C::col_ptr[bc + 1] - k0;
-                        const T l = active ? (T)llr[frame * n + bc * Z + z] : (T)0;
+                        T l;
+                        if constexpr (FUSED) l = active ? (T)mine[f * n + bc * Z + z] : (T)0;
+                        else l = active ? (T)llr[frame * n + bc * Z + z] : (T)0;
                         L[j] = l;
                         own[j] = l;
                         if (lane_on) hb_b[bc * Z + z1] = (uint8_t)!(l > (T)0);  // idle lanes alias lane 0
@@ -73,7 +89,7 @@ spec_spaw_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t
                 });
             }
         });
-        if (threadIdx.x < 16) flags[threadIdx.x] = 0;
+        if (threadIdx.x < 24) flags[threadIdx.x] = 0;
         __syncthreads();
 
         bool done = !active;
@@ -216,7 +232,26 @@ spec_spaw_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t
             }
             __syncthreads();
         }
-        if (active) {
+        // ---- results: every wave writes its own columns (fused: counts their bit errors)
+        if constexpr (FUSED) {
+            unsigned errs = 0;
+            if (active) {
+                const uint8_t *rf = sweep_slice_ref<n, F>(mine) + f * n;  // the frame's transmitted bits, staged beside its LLRs
+                static_for<0, W>([&](auto w) {
+                    if (wave == w) {
+                        static_for<0, NBW>([&](auto j) {
+                            if constexpr (j < PL::COLS.cnt[w]) {
+                                constexpr int bc = PL::COLS.item[w][j];
+                                errs += hard_bit<RULE>(own[j]) != (unsigned)rf[bc * Z + z];
+                            }
+                        });
+                    }
+                });
+            }
+            if (errs) flags[16 + f] = 1;
+            __syncthreads();
+            if (active) acc.book(errs, flags[16 + f] != 0, wave == 0 && z == 0, res_iters, res_conv);
+        } else if (active) {
             static_for<0, W>([&](auto w) {
                 if (wave == w) {
                     static_for<0, NBW>([&](auto j) {
@@ -232,6 +267,7 @@ spec_spaw_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t
         }
         __syncthreads();
     }
+    if constexpr (FUSED) acc.flush_wave(sp.counters);
 }
 
 // ------------------------------------------------------------------------------ independent slots
@@ -243,7 +279,8 @@ spec_spaw_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t
 template <int RULE, class C, typename T, typename TL, int F, int W, bool REF = false>
 __global__ void __launch_bounds__(64 * W * ((F * C::Z + 63) / 64))
 spec_spaw_slots_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t *__restrict__ hard_out,
-                       int *__restrict__ iters_out, uint8_t *__restrict__ conv_out, T *__restrict__ post_out)
+                       int *__restrict__ iters_out, uint8_t *__restrict__ conv_out, T *__restrict__ post_out, SweepDev,
+                       float *)  // the last two: spec_spaw_kernel's signature, unused here
 {
     typedef SpawLayout<C, T, F> LY;
     typedef R1wPlan<C, W> PL;
@@ -464,8 +501,15 @@ spec_spaw_slots_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, u
 template <class C>
 constexpr bool spaw_refresh_built() { return C::EB > 100; }
 
+#ifdef LDPC_SPEC_FUSED
+constexpr bool kFused = true;
+#else
+constexpr bool kFused = false;
+#endif
+
 template <int RULE, class C, typename T, typename TL, int F, int W>
-static hipError_t launch_spaw(const ldpc_decode_config &cfg, const Launch &io, int num_cus, const char **name, bool *supported)
+static hipError_t launch_spaw(const ldpc_decode_config &cfg, const Launch &io, int num_cus, const char **name, bool *supported,
+                              const SweepDev *sp = nullptr, Scratch *ws = nullptr)
 {
     typedef SpawLayout<C, T, F> LY;
     constexpr int G = (LY::LANES + 63) / 64;
@@ -475,34 +519,57 @@ static hipError_t launch_spaw(const ldpc_decode_config &cfg, const Launch &io, i
     g.float_syndrome0 = 0; g.num_active_checks = -1; g.num_refresh_vars = bounded ? cfg.num_refresh_vars : -1;
     g.scale = (T)cfg.scale; g.clip_tanh_arg = (T)cfg.clip_tanh_arg; g.clip_prod = (T)cfg.clip_prod;
     g.clip_post = (T)cfg.clip_post; g.offset = (T)cfg.offset;
-    auto k = spec_spaw_kernel<RULE, C, T, TL, F, W>;
-    if constexpr (F > 1) {  // early exit with several slots: every slot runs its own queue of frames
-        if (cfg.early_exit && cfg.max_iters >= 1) k = spec_spaw_slots_kernel<RULE, C, T, TL, F, W>;
-    }
-    if (bounded) {
-        if constexpr (spaw_refresh_built<C>()) {
-            k = spec_spaw_kernel<RULE, C, T, TL, F, W, true>;
-            if constexpr (F > 1) {
-                if (cfg.early_exit && cfg.max_iters >= 1) k = spec_spaw_slots_kernel<RULE, C, T, TL, F, W, true>;
-            }
+    if constexpr (kFused) {  // fused sweep: float LLRs drawn in the kernel, no loop bound; the slots start and end together
+        if constexpr (sizeof(TL) == 4 && (C::NB * C::Z) % 4 == 0) {
+            if (bounded || !sp || !ws) { *supported = false; return hipSuccess; }
+            auto kf = spec_spaw_kernel<RULE, C, T, TL, F, W, false, true>;
+            int per_cu = 0;
+            hipError_t e = kernel_setup(reinterpret_cast<const void *>(kf), 64 * W * G, LY::LDS_BYTES, &per_cu);
+            if (e != hipSuccess) return e;
+            if (per_cu < 1) per_cu = 1;
+            const long long groups = (io.frames + F - 1) / F, full = (long long)num_cus * per_cu * 2;
+            long long grid = full > groups ? groups : full;
+            if (grid < 1) grid = 1;
+            e = scratch_reserve(*ws, sweep_slice_bytes<C::NB * C::Z, F>(), full, grid);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(64 * W * G), LY::LDS_BYTES, io.stream, g, nullptr, io.frames, nullptr,
+                               nullptr, nullptr, nullptr, *sp, reinterpret_cast<float *>(ws->ptr));
+            *name = sizeof(T) == 8 ? "fused_spec_spaw_f64" : "fused_spec_spaw_f32";
+            return hipGetLastError();
         } else {
             *supported = false;
             return hipSuccess;
         }
+    } else {
+        auto k = spec_spaw_kernel<RULE, C, T, TL, F, W>;
+        if constexpr (F > 1) {  // early exit with several slots: every slot runs its own queue of frames
+            if (cfg.early_exit && cfg.max_iters >= 1) k = spec_spaw_slots_kernel<RULE, C, T, TL, F, W>;
+        }
+        if (bounded) {
+            if constexpr (spaw_refresh_built<C>()) {
+                k = spec_spaw_kernel<RULE, C, T, TL, F, W, true>;
+                if constexpr (F > 1) {
+                    if (cfg.early_exit && cfg.max_iters >= 1) k = spec_spaw_slots_kernel<RULE, C, T, TL, F, W, true>;
+                }
+            } else {
+                *supported = false;
+                return hipSuccess;
+            }
+        }
+        int per_cu = 0;
+        hipError_t e = kernel_setup(reinterpret_cast<const void *>(k), 64 * W * G, LY::LDS_BYTES, &per_cu);
+        if (e != hipSuccess) return e;
+        if (per_cu < 1) per_cu = 1;
+        const long long groups = (io.frames + F - 1) / F;
+        long long grid = (long long)num_cus * per_cu * 2;
+        if (grid > groups) grid = groups;
+        if (grid < 1) grid = 1;
+        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(64 * W * G), LY::LDS_BYTES, io.stream, g,
+                           reinterpret_cast<const TL *>(io.llr), io.frames, io.hard, io.iters, io.converged,
+                           reinterpret_cast<T *>(io.posterior), SweepDev{}, nullptr);
+        *name = sizeof(T) == 8 ? "spec_spaw_f64" : "spec_spaw_f32";
+        return hipGetLastError();
     }
-    int per_cu = 0;
-    hipError_t e = kernel_setup(reinterpret_cast<const void *>(k), 64 * W * G, LY::LDS_BYTES, &per_cu);
-    if (e != hipSuccess) return e;
-    if (per_cu < 1) per_cu = 1;
-    const long long groups = (io.frames + F - 1) / F;
-    long long grid = (long long)num_cus * per_cu * 2;
-    if (grid > groups) grid = groups;
-    if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(64 * W * G), LY::LDS_BYTES, io.stream, g,
-                       reinterpret_cast<const TL *>(io.llr), io.frames, io.hard, io.iters, io.converged,
-                       reinterpret_cast<T *>(io.posterior));
-    *name = sizeof(T) == 8 ? "spec_spaw_f64" : "spec_spaw_f32";
-    return hipGetLastError();
 }
 
 // Codes and arithmetic types that come here: see the head of this file.
@@ -533,21 +600,23 @@ constexpr int spaw_slots()
 
 template <int RULE, class C, int SLOTS>
 static hipError_t launch_spaw_rule(const ldpc_decode_config &cfg, int compute_dtype, const Launch &io, int num_cus,
-                                   const char **name, bool *supported)
+                                   const char **name, bool *supported, const SweepDev *sp = nullptr, Scratch *ws = nullptr)
 {
     constexpr int FD = spaw_slots<C, double, SLOTS>(), FF = spaw_slots<C, float, SLOTS>();
     *supported = true;
     if constexpr (spaw_wanted<C, double, FD>()) {
         constexpr int W = FD * C::Z > 64 ? LDPC_SPAW_WAVES_PACKED : LDPC_SPAW_WAVES;
         if (compute_dtype == LDPC_F64) {
-            if (io.llr_dtype == LDPC_F64) return launch_spaw<RULE, C, double, double, FD, W>(cfg, io, num_cus, name, supported);
-            return launch_spaw<RULE, C, double, float, FD, W>(cfg, io, num_cus, name, supported);
+            if constexpr (!kFused) {
+                if (io.llr_dtype == LDPC_F64) return launch_spaw<RULE, C, double, double, FD, W>(cfg, io, num_cus, name, supported);
+            }
+            return launch_spaw<RULE, C, double, float, FD, W>(cfg, io, num_cus, name, supported, sp, ws);
         }
     }
     if constexpr (spaw_wanted<C, float, FF>()) {
         constexpr int W = FF * C::Z > 64 ? LDPC_SPAW_WAVES_PACKED : LDPC_SPAW_WAVES;
-        if (compute_dtype == LDPC_F32 && io.llr_dtype == LDPC_F32)
-            return launch_spaw<RULE, C, float, float, FF, W>(cfg, io, num_cus, name, supported);
+        if (compute_dtype == LDPC_F32 && (kFused || io.llr_dtype == LDPC_F32))
+            return launch_spaw<RULE, C, float, float, FF, W>(cfg, io, num_cus, name, supported, sp, ws);
     }
     *supported = false;
     return hipSuccess;
@@ -560,6 +629,25 @@ static hipError_t launch_spaw_rule(const ldpc_decode_config &cfg, int compute_dt
 #define LDPC_SPAW_CAT2(a, b) a##b
 #define LDPC_SPAW_CAT(a, b) LDPC_SPAW_CAT2(a, b)
 
+#ifdef LDPC_SPEC_FUSED
+// the same kernels as one launch of channel + decode + error accounting (ldpc_sweep_batch)
+hipError_t LDPC_SPAW_CAT(launch_spec_spaw_fused_rule_, LDPC_SPAW_RULE)(int spec_id, const ldpc_decode_config &cfg,
+                                                                       int compute_dtype, const Launch &io, const SweepDev &sp,
+                                                                       int num_cus, Scratch &workspace, const char **name,
+                                                                       bool *supported)
+{
+    int id = 0;
+#define LDPC_LAUNCH(CODE, SLOTS)                                                                   \
+    if (spec_id == id) {                                                                           \
+        return launch_spaw_rule<LDPC_SPAW_RULE, CODE, SLOTS>(cfg, compute_dtype, io, num_cus, name, supported, &sp, &workspace); \
+    }                                                                                              \
+    ++id;
+    LDPC_FOR_EACH_SPEC_CODE(LDPC_LAUNCH)
+#undef LDPC_LAUNCH
+    *supported = false;
+    return hipSuccess;
+}
+#else
 hipError_t LDPC_SPAW_CAT(launch_spec_spaw_rule_, LDPC_SPAW_RULE)(int spec_id, const ldpc_decode_config &cfg,
                                                                  int compute_dtype, const Launch &io, int num_cus,
                                                                  const char **name, bool *supported)
@@ -575,5 +663,6 @@ hipError_t LDPC_SPAW_CAT(launch_spec_spaw_rule_, LDPC_SPAW_RULE)(int spec_id, co
     *supported = false;
     return hipSuccess;
 }
+#endif
 
 }  // namespace ldpc

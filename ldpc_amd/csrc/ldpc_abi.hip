@@ -822,9 +822,10 @@ static int sweep_impl(ldpc_code *c, const ldpc_decode_config *cfg, const ldpc_ch
     HIP_TRY(hipSetDevice(c->device));
     const bool quirks = (cfg->num_active_checks >= 0 && cfg->num_active_checks < c->m) ||
                         (cfg->num_refresh_vars >= 0 && cfg->num_refresh_vars < c->n);
-    if (c->spec_id < 0 || !c->has_qc || quirks || cfg->clip_post > 0.0)
-        return fail(LDPC_ERR_UNSUPPORTED, "the fused sweep serves compiled-in codes without loop-bound quirks or posterior clip; "
-                                          "use ldpc_channel_llr + ldpc_decode_batch + ldpc_count_errors");
+    const bool spa = cfg->rule >= 2 && cfg->rule <= 4;  // the sum-product kernels apply the posterior clip themselves
+    if (c->spec_id < 0 || !c->has_qc || quirks || (cfg->clip_post > 0.0 && !spa))
+        return fail(LDPC_ERR_UNSUPPORTED, "the fused sweep serves compiled-in codes without loop-bound quirks (and, for the min-sum rules, "
+                                          "without posterior clip); use ldpc_channel_llr + ldpc_decode_batch + ldpc_count_errors");
     SweepDev sp;
     sp.ch = make_channel_dev(ch->sigma2, ch->gain, ch->plus_is_bit != 0, ch->prefix_len, ch->prefix_llr, ch->seed,
                              ch->first_frame, ch->cfo_cycles_per_symbol, ch->phase0_cycles);
@@ -834,16 +835,28 @@ static int sweep_impl(ldpc_code *c, const ldpc_decode_config *cfg, const ldpc_ch
     sp.counters = reinterpret_cast<unsigned long long *>(counters_dev);
     Launch io{nullptr, LDPC_F32, (long long)frames, nullptr, nullptr, nullptr, nullptr, reinterpret_cast<hipStream_t>(stream)};
     bool supported = false;
-    hipError_t e = compute_dtype == LDPC_F16
-                       ? (cfg->rule == LDPC_RULE_LNMS
-                              ? launch_spec_lnms_half_fused(c->spec_id, *cfg, io, sp, c->num_cus, c->workspace_for(io.stream), &g_kernel, &supported)
-                              : launch_spec_half_fused(c->spec_id, *cfg, io, sp, c->num_cus, &g_kernel, &supported))
-                       : launch_spec_fused(c->spec_id, *cfg, compute_dtype, io, sp, c->num_cus, c->workspace_for(io.stream),
-                                           &g_kernel, &supported);
-    if (e == hipSuccess && !supported && compute_dtype != LDPC_F16) {  // the multi-wave flooding kernels
-        if (cfg->rule == 0) e = launch_spec_r0w_fused(c->spec_id, *cfg, compute_dtype, io, sp, c->num_cus, c->workspace_for(io.stream), &g_kernel, &supported);
-        else if (cfg->rule == 1) e = launch_spec_r1w_fused(c->spec_id, *cfg, compute_dtype, io, sp, c->num_cus, c->workspace_for(io.stream), &g_kernel, &supported);
-        else if (cfg->rule == LDPC_RULE_OMS) e = launch_spec_omsw_fused(c->spec_id, *cfg, compute_dtype, io, sp, c->num_cus, c->workspace_for(io.stream), &g_kernel, &supported);
+    hipError_t e = hipSuccess;
+    if (spa) {  // sum-product: the single-wave kernel where it serves the code, else the multi-wave one
+        if (compute_dtype != LDPC_F16) {
+            e = launch_spec_spa_fused(c->spec_id, *cfg, compute_dtype, io, sp, c->num_cus, &g_kernel, &supported);
+            if (e == hipSuccess && !supported) {
+                Scratch &ws = c->workspace_for(io.stream);
+                e = cfg->rule == 2   ? launch_spec_spaw_fused_rule_2(c->spec_id, *cfg, compute_dtype, io, sp, c->num_cus, ws, &g_kernel, &supported)
+                    : cfg->rule == 3 ? launch_spec_spaw_fused_rule_3(c->spec_id, *cfg, compute_dtype, io, sp, c->num_cus, ws, &g_kernel, &supported)
+                                     : launch_spec_spaw_fused_rule_4(c->spec_id, *cfg, compute_dtype, io, sp, c->num_cus, ws, &g_kernel, &supported);
+            }
+        }
+    } else if (compute_dtype == LDPC_F16) {
+        e = cfg->rule == LDPC_RULE_LNMS
+                ? launch_spec_lnms_half_fused(c->spec_id, *cfg, io, sp, c->num_cus, c->workspace_for(io.stream), &g_kernel, &supported)
+                : launch_spec_half_fused(c->spec_id, *cfg, io, sp, c->num_cus, &g_kernel, &supported);
+    } else {
+        e = launch_spec_fused(c->spec_id, *cfg, compute_dtype, io, sp, c->num_cus, c->workspace_for(io.stream), &g_kernel, &supported);
+        if (e == hipSuccess && !supported) {  // the multi-wave flooding kernels
+            if (cfg->rule == 0) e = launch_spec_r0w_fused(c->spec_id, *cfg, compute_dtype, io, sp, c->num_cus, c->workspace_for(io.stream), &g_kernel, &supported);
+            else if (cfg->rule == 1) e = launch_spec_r1w_fused(c->spec_id, *cfg, compute_dtype, io, sp, c->num_cus, c->workspace_for(io.stream), &g_kernel, &supported);
+            else if (cfg->rule == LDPC_RULE_OMS) e = launch_spec_omsw_fused(c->spec_id, *cfg, compute_dtype, io, sp, c->num_cus, c->workspace_for(io.stream), &g_kernel, &supported);
+        }
     }
     if (e != hipSuccess) return fail(LDPC_ERR_HIP, "fused sweep launch: %s", hipGetErrorString(e));
     if (!supported)

@@ -240,6 +240,15 @@ hipError_t launch_spec_r1w_fused(int spec_id, const ldpc_decode_config &cfg, int
                                  int num_cus, Scratch &workspace, const char **kernel_name, bool *supported);
 hipError_t launch_spec_omsw_fused(int spec_id, const ldpc_decode_config &cfg, int compute_dtype, const Launch &io, const SweepDev &sp,
                                   int num_cus, Scratch &workspace, const char **kernel_name, bool *supported);
+// decode_spec_spa.hip / decode_spec_spaw.hip: the sum-product rules R2, R3, R4 (single wave; several waves per frame group)
+hipError_t launch_spec_spa_fused(int spec_id, const ldpc_decode_config &cfg, int compute_dtype, const Launch &io, const SweepDev &sp,
+                                 int num_cus, const char **kernel_name, bool *supported);
+hipError_t launch_spec_spaw_fused_rule_2(int spec_id, const ldpc_decode_config &cfg, int compute_dtype, const Launch &io, const SweepDev &sp,
+                                         int num_cus, Scratch &workspace, const char **kernel_name, bool *supported);
+hipError_t launch_spec_spaw_fused_rule_3(int spec_id, const ldpc_decode_config &cfg, int compute_dtype, const Launch &io, const SweepDev &sp,
+                                         int num_cus, Scratch &workspace, const char **kernel_name, bool *supported);
+hipError_t launch_spec_spaw_fused_rule_4(int spec_id, const ldpc_decode_config &cfg, int compute_dtype, const Launch &io, const SweepDev &sp,
+                                         int num_cus, Scratch &workspace, const char **kernel_name, bool *supported);
 // decode_lnms_h.hip: the layered rule in packed half precision
 hipError_t launch_spec_lnms_half_fused(int spec_id, const ldpc_decode_config &cfg, const Launch &io, const SweepDev &sp,
                                        int num_cus, Scratch &workspace, const char **kernel_name, bool *supported);

@@ -51,6 +51,65 @@ def test_fused_counters_equal_three_launches(name, rule, snr, frames):
                 assert 0 < fused[1] < frames, fused        # the batch straddles the waterfall
 
 
+#: sum-product rules (code, rule, Es/N0 dB, frames, kernel family): the single-wave kernel on the small codes, the
+#: multi-wave one on 802.11n in double and on the 5G matrices
+SPA_CASES = [("ccsds512", "R2", -0.5, 20_001, "spa"), ("ccsds512", "R3", -0.5, 20_000, "spa"), ("ccsds512", "R4", -0.5, 10_001, "spa"),
+             ("wifi648", "R3", -1.0, 10_001, "spa/spaw"), ("wifi648", "R2", -1.0, 5_000, "spa/spaw"),
+             ("nr_bg2_z40", "R3", -6.0, 3_001, "spaw"), ("nr_bg2_z40", "R2", -6.0, 2_000, "spaw"),
+             ("nr_bg2_z40", "R4", -6.0, 1_501, "spaw"), ("nr_bg2_z40_r1400", "R3", -4.5, 2_002, "spaw")]
+
+
+@pytest.mark.parametrize("name,rule,snr,frames,family", SPA_CASES, ids=[f"{c[0]}-{c[1]}" for c in SPA_CASES])
+def test_fused_sum_product_counters_equal_three_launches(name, rule, snr, frames, family):
+    """Rules R2, R3, R4 (bpsk.py:263-387, channel.py:402-513, 260-398) with their posterior clips: one launch
+    against three, both arithmetic types, early exit and fixed work, with and without a carrier offset
+    (the channel of BASELINE configuration 5)."""
+    import torch
+    from ldpc_amd import channel
+    dev = torch.device("cuda", 0)
+    code = codes.load_packaged(name)
+    G = codes.load_packaged_generator(name) if name in ("ccsds512", "wifi648") else None
+    doppler = dict(cfo=channel.doppler_cfo(4000.0, compensated=0.999), phase0=0.05)
+    for dtype in (np.float64, np.float32):
+        for cfg, kw in ((config.PRESETS[rule].with_(max_iters=12), {}), (config.PRESETS[rule].with_(max_iters=5, early_exit=False), {}),
+                        (config.PRESETS[rule].with_(max_iters=12), doppler)):
+            n_fr = frames if dtype is np.float32 or not kw else frames // 2
+            kernel, fused, three = _both(code, G, cfg, snr, n_fr, dtype, dev, **kw)
+            want = {"spa": ("fused_spec_spa_",), "spaw": ("fused_spec_spaw_",), "spa/spaw": ("fused_spec_spa_", "fused_spec_spaw_")}[family]
+            assert kernel.startswith(want), kernel
+            assert kernel.endswith("f64" if dtype is np.float64 else "f32"), kernel
+            assert fused.tolist() == three.tolist(), (kernel, cfg.early_exit, kw, fused, three)
+            assert fused[0] == n_fr
+            if cfg.early_exit:
+                assert 0 < fused[1] < n_fr, fused        # the batch straddles the waterfall
+
+
+def test_fused_sum_product_packed_words_and_ragged_tail():
+    """Packed reference words and frame counts that leave slots of the last workgroup idle."""
+    import torch
+    from ldpc_amd import sweep
+    from ldpc_amd.decoder import Decoder
+    dev = torch.device("cuda", 0)
+    for name, frames in (("ccsds512", 1), ("ccsds512", 257), ("nr_bg2_z40", 1), ("nr_bg2_z40", 1_000)):
+        code = codes.load_packaged(name)
+        G = codes.load_packaged_generator(name) if name == "ccsds512" else None
+        dec = Decoder(code)
+        cfg = config.R3.with_(max_iters=10)
+        cw = sweep.make_codewords(code, G, frames, [61], dev)
+        a = torch.zeros((5,), dtype=torch.int64, device=dev)
+        b = torch.zeros((5,), dtype=torch.int64, device=dev)
+        snr = -0.5 if name == "ccsds512" else -6.0
+        ka = sweep.sweep_fused(dec, cw, snr, cfg, [62], a, compute_dtype=np.float32, first_frame=11)
+        kb = sweep.sweep_fused(dec, sweep.pack_bits(cw), snr, cfg, [62], b, compute_dtype=np.float32, first_frame=11, packed_n=code.n)
+        bt = sweep.noisy_batch(code, cw, snr, cfg, [62], dev, first_frame=11)
+        sweep.decode_batch(dec, bt, cfg, compute_dtype=np.float32)
+        sweep.count_errors(dec, bt)
+        torch.cuda.synchronize()
+        assert ka == kb and ka.startswith("fused_spec_spa"), (ka, kb)
+        assert a.cpu().numpy().tolist() == b.cpu().numpy().tolist() == bt.counters.cpu().numpy().tolist(), (name, frames, a, b, bt.counters)
+        assert a[0] == frames
+
+
 @pytest.mark.parametrize("frames", [40_001, 7])
 def test_fused_half_precision_counters_equal_three_launches(frames):
     """Rule R1 in packed half precision (two frames per lane): the fused launch stages both frames of
@@ -199,12 +258,17 @@ def test_ber_sweep_fused_equals_unfused_and_unsupported_falls_back():
     a = sweep.ber_sweep(code, G, config.R0, snrs, 100_000, dev, np.float64, seed=4, fused=True)
     b = sweep.ber_sweep(code, G, config.R0, snrs, 100_000, dev, np.float64, seed=4, fused=False)
     assert a == b
-    # the sum-product rules have no fused kernel: "auto" falls back, True raises
+    # the sum-product rules through the sweep: fused by default, same counters as three launches
     c = sweep.ber_sweep(code, G, config.R3, [1.0], 5_000, dev, np.float32, seed=4)
     d = sweep.ber_sweep(code, G, config.R3, [1.0], 5_000, dev, np.float32, seed=4, fused=False)
     assert c == d
+    # a loop bound of the reference (channel.py:646) has no fused kernel: "auto" falls back, True raises
+    bounded = config.R3.with_(num_refresh_vars=300)
+    c = sweep.ber_sweep(code, G, bounded, [1.0], 5_000, dev, np.float32, seed=4)
+    d = sweep.ber_sweep(code, G, bounded, [1.0], 5_000, dev, np.float32, seed=4, fused=False)
+    assert c == d
     with pytest.raises(_lib.LdpcError) as ei:
-        sweep.ber_sweep(code, G, config.R3, [1.0], 5_000, dev, np.float32, seed=4, fused=True)
+        sweep.ber_sweep(code, G, bounded, [1.0], 5_000, dev, np.float32, seed=4, fused=True)
     assert ei.value.code == _lib.LDPC_ERR_UNSUPPORTED
     # a matrix that is not compiled in
     other = codes.compile_code(np.roll(code.dense(), 1, axis=1), "rolled")
