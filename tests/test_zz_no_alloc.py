@@ -1,5 +1,6 @@
 """ldpc_decode_batch_noalloc against ldpc_decode_batch, through the C ABI, for the two kernel
-families that keep frame state in global scratch memory; two calls in a row, the second smaller."""
+families that keep frame state in global scratch memory; two calls in a row, the second smaller.  And the
+call captured into a HIP graph (one of the callers it exists for) and replayed."""
 import numpy as np
 import pytest
 
@@ -76,3 +77,53 @@ def test_noalloc_serves_on_chip_kernels_and_refuses_oversize():
     with pytest.raises(_lib.LdpcError) as err:
         _run(bdec, Lb, config.R1.with_(max_iters=1), np.float64, _lib.KERNEL_CSR, noalloc=True)
     assert err.value.code == _lib.LDPC_ERR_UNSUPPORTED and "allocation-free" in str(err.value)
+
+
+@pytest.mark.parametrize("name,rule,kernel,compute,expect,frames", [
+    ("ccsds512", "R0", _lib.KERNEL_AUTO, np.float64, "spec_r0_f64", 1000),          # state on chip
+    ("nr_bg1_z384", "LNMS", _lib.KERNEL_AUTO, np.float32, "spec_lnms_f32", 33),
+    ("nr_bg1_z384", "R1", _lib.KERNEL_CSR, np.float64, "csr_global_all_f64", 20),   # state in the fixed scratch array
+])
+def test_noalloc_under_graph_capture(name, rule, kernel, compute, expect, frames):
+    """One warm-up call outside capture (symbol address, kernel attributes), then the call is captured into a
+    HIP graph; replays on new LLRs in the same buffers give what ldpc_decode_batch gives."""
+    import torch
+    dev = torch.device("cuda", 0)
+    code = codes.load_packaged(name)
+    dec = Decoder(code)
+    cfg = config.PRESETS[rule].with_(max_iters=6)
+    rng = np.random.default_rng(8)
+
+    def draw():
+        L = (2.2 * (1.0 + 0.6 * rng.standard_normal((frames, code.n)))).astype(np.float32)
+        return -L if cfg.plus_is_bit else L
+
+    llr = torch.as_tensor(draw(), device=dev)
+    hard = torch.zeros((frames, code.n), dtype=torch.uint8, device=dev)
+    iters = torch.zeros((frames,), dtype=torch.int32, device=dev)
+    conv = torch.zeros((frames,), dtype=torch.uint8, device=dev)
+
+    def call(noalloc, h=hard, i=iters, c=conv):
+        return dec.decode_device(llr.data_ptr(), np.float32, frames, h.data_ptr(), i.data_ptr(), c.data_ptr(), cfg,
+                                 compute_dtype=compute, stream=torch.cuda.current_stream().cuda_stream, kernel=kernel,
+                                 noalloc=noalloc)
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        assert call(True) == expect          # warm-up on the capture stream, outside capture
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        call(True)
+    for _ in range(2):
+        llr.copy_(torch.as_tensor(draw(), device=dev))
+        hard.fill_(9); iters.fill_(-1); conv.fill_(9)
+        graph.replay()
+        torch.cuda.synchronize()
+        h2, i2, c2 = torch.empty_like(hard), torch.empty_like(iters), torch.empty_like(conv)
+        call(False, h2, i2, c2)
+        torch.cuda.synchronize()
+        assert torch.equal(hard, h2) and torch.equal(iters, i2) and torch.equal(conv, c2)
+        assert (hard <= 1).all() and (iters >= 0).all()
