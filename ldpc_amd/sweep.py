@@ -303,9 +303,9 @@ SWEEP_CHUNK = 1 << 14
 def ber_sweep(code: CompiledCode, G: Optional[np.ndarray], cfg: DecodeConfig, snrs_db, frames_per_point: int,
               device, compute_dtype=np.float64, seed=0, dec: Optional[Decoder] = None, batch: int = 1 << 18,
               rank: Optional[int] = None, world: Optional[int] = None, reduce: bool = True,
-              compat_prefix: bool = False, fused="auto"):
+              compat_prefix: bool = False, fused="auto", cfo: float = 0.0, phase0: float = 0.0):
     """Monte-Carlo error-rate sweep, the batched form of the reference's ``plotFrameError``
-    (ldpc.py:637-667).  ``fused``: True = channel, decode and counting in one launch per batch
+    (ldpc.py:637-667).  ``cfo`` / ``phase0``: the Doppler-shifted channel of ``noisy_batch``.  ``fused``: True = channel, decode and counting in one launch per batch
     (``ldpc_sweep_batch``; an error where no fused kernel exists), False = three launches, "auto" =
     fused where a kernel exists.  The counters are the same either way.  The ``frames_per_point`` frames of an SNR point are numbered 0, 1, ...; rank r
     of ``world`` decodes the contiguous range ``shard_range(frames_per_point, r, world)`` of them,
@@ -330,7 +330,7 @@ def ber_sweep(code: CompiledCode, G: Optional[np.ndarray], cfg: DecodeConfig, sn
                 cw = codewords_range(code, G, pos, end, frames_per_point, [seed, si], device)
                 try:
                     sweep_fused(dec, cw, float(snr), cfg, [seed, si], total, compute_dtype=compute_dtype,
-                                first_frame=pos, compat_prefix=compat_prefix)
+                                first_frame=pos, compat_prefix=compat_prefix, cfo=cfo, phase0=phase0)
                     done = True
                 except LdpcError as e:
                     if fused is True or e.code != LDPC_ERR_UNSUPPORTED:
@@ -338,7 +338,7 @@ def ber_sweep(code: CompiledCode, G: Optional[np.ndarray], cfg: DecodeConfig, sn
                     fused = False
             if not done:
                 bt = make_batch_range(code, G, pos, end, frames_per_point, float(snr), cfg, seed=[seed, si], device=device,
-                                      compat_prefix=compat_prefix)
+                                      compat_prefix=compat_prefix, cfo=cfo, phase0=phase0)
                 decode_batch(dec, bt, cfg, compute_dtype=compute_dtype)
                 count_errors(dec, bt)
                 total += bt.counters
@@ -370,11 +370,12 @@ def codewords_range(code: CompiledCode, G, first: int, last: int, total: int, se
 
 
 def make_batch_range(code: CompiledCode, G, first: int, last: int, total: int, snr_db: float, cfg: DecodeConfig,
-                     seed, device, llr_dtype=None, compat_prefix: bool = False) -> DeviceBatch:
+                     seed, device, llr_dtype=None, compat_prefix: bool = False, cfo: float = 0.0,
+                     phase0: float = 0.0) -> DeviceBatch:
     """The frames [first, last) of a sweep point of ``total`` frames.  Codewords come from
     ``codewords_range``, noise from the library's channel kernel keyed by the absolute frame number:
     the result does not depend on how the point is cut into ranges."""
     seed = list(np.atleast_1d(seed))
     cw = codewords_range(code, G, first, last, total, seed, device)
     return noisy_batch(code, cw, snr_db, cfg, seed, device, llr_dtype=llr_dtype, first_frame=first,
-                       compat_prefix=compat_prefix)
+                       compat_prefix=compat_prefix, cfo=cfo, phase0=phase0)

@@ -262,6 +262,11 @@ def test_ber_sweep_fused_equals_unfused_and_unsupported_falls_back():
     c = sweep.ber_sweep(code, G, config.R3, [1.0], 5_000, dev, np.float32, seed=4)
     d = sweep.ber_sweep(code, G, config.R3, [1.0], 5_000, dev, np.float32, seed=4, fused=False)
     assert c == d
+    from ldpc_amd import channel
+    cfo = channel.doppler_cfo(4000.0, compensated=0.999)   # the Doppler-shifted channel through the sweep
+    e = sweep.ber_sweep(code, G, config.R3, [1.0], 5_000, dev, np.float32, seed=4, cfo=cfo, phase0=0.1)
+    f = sweep.ber_sweep(code, G, config.R3, [1.0], 5_000, dev, np.float32, seed=4, cfo=cfo, phase0=0.1, fused=False)
+    assert e == f and e != c
     # a loop bound of the reference (channel.py:646) has no fused kernel: "auto" falls back, True raises
     bounded = config.R3.with_(num_refresh_vars=300)
     c = sweep.ber_sweep(code, G, bounded, [1.0], 5_000, dev, np.float32, seed=4)
