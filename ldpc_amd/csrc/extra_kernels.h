@@ -21,6 +21,14 @@ struct EncDev {
     const int *step_ptr;      // [n_steps + 1] its terms
     const int *step_level;    // [n_steps] non-decreasing; a step reads columns of earlier levels only
     const unsigned *terms;    // block column << 16 | shift
+    // lifting sizes that are multiples of four (the word-wide kernel; NULL / 0 otherwise).  Only columns that some
+    // term reads get a place ("slot") in LDS; slot n_slots4 stays zero.  Every step's terms are padded to a
+    // multiple of four with terms that read the zero slot.
+    int n_slots4;
+    const int *info_slot4;    // [k_cols] slot of an information column, -1 = nothing reads it
+    const int *step_slot4;    // [n_steps] slot of a step's output, -1 = nothing reads it
+    const int *step_ptr4;     // [n_steps + 1], multiples of four
+    const unsigned *terms4;   // slot << 16 | shift; 16-byte aligned
 };
 hipError_t launch_encode_qc(const EncDev &e, const uint8_t *msg, long long frames, uint8_t *cw, int num_cus,
                             hipStream_t stream, bool *supported, unsigned long long seed, unsigned long long first_frame,

@@ -676,6 +676,30 @@ extern "C" int32_t ldpc_encoder_create(int32_t Z, int32_t n_cols, int32_t nb, in
     host.insert(host.end(), step_ptr, step_ptr + n_steps + 1);
     host.insert(host.end(), step_level, step_level + n_steps);
     for (int t = 0; t < n_terms; ++t) host.push_back((int)(((unsigned)term_col[t] << 16) | (unsigned)term_shift[t]));
+    // the word-wide kernel's copy of the schedule (see EncDev)
+    const bool words4 = Z % 4 == 0 && Z >= 8 && n_cols < 65535;
+    size_t ptr4_at = 0, terms4_at = 0, islot_at = 0, sslot_at = 0;
+    int n_slots = 0;
+    if (words4) {
+        std::vector<int> slot(n_cols, -1);  // LDS places go to the columns that are read
+        for (int t = 0; t < n_terms; ++t)
+            if (slot[term_col[t]] < 0) slot[term_col[t]] = n_slots++;
+        islot_at = host.size();
+        for (int j = 0; j < k_cols; ++j) host.push_back(slot[info_cols[j]]);
+        sslot_at = host.size();
+        for (int s = 0; s < n_steps; ++s) host.push_back(slot[step_out[s]]);
+        ptr4_at = host.size();
+        std::vector<int> padded;
+        for (int s = 0; s < n_steps; ++s) {
+            host.push_back((int)padded.size());
+            for (int t = step_ptr[s]; t < step_ptr[s + 1]; ++t) padded.push_back((int)(((unsigned)slot[term_col[t]] << 16) | (unsigned)term_shift[t]));
+            while (padded.size() % 4) padded.push_back((int)((unsigned)n_slots << 16));
+        }
+        host.push_back((int)padded.size());
+        while (host.size() % 4) host.push_back(0);
+        terms4_at = host.size();
+        host.insert(host.end(), padded.begin(), padded.end());
+    }
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&enc->d_ints), host.size() * sizeof(int) + 16));
     hipError_t e = hipMemcpy(enc->d_ints, host.data(), host.size() * sizeof(int), hipMemcpyHostToDevice);
     if (e != hipSuccess) { (void)hipFree(enc->d_ints); return fail(LDPC_ERR_HIP, "encoder tables: %s", hipGetErrorString(e)); }
@@ -686,6 +710,11 @@ extern "C" int32_t ldpc_encoder_create(int32_t Z, int32_t n_cols, int32_t nb, in
     d.step_ptr = d.step_out + n_steps;
     d.step_level = d.step_ptr + n_steps + 1;
     d.terms = reinterpret_cast<const unsigned *>(d.step_level + n_steps);
+    d.n_slots4 = words4 ? n_slots : 0;
+    d.info_slot4 = words4 ? enc->d_ints + islot_at : nullptr;
+    d.step_slot4 = words4 ? enc->d_ints + sslot_at : nullptr;
+    d.step_ptr4 = words4 ? enc->d_ints + ptr4_at : nullptr;
+    d.terms4 = words4 ? reinterpret_cast<const unsigned *>(enc->d_ints + terms4_at) : nullptr;
     // a schedule with many taps per (output, input) column pair and Z <= 64 runs on ballot masks
     // (its kernel holds 256 column masks and the random words of 4096 message bits)
     if (Z <= 64 && n_cols <= 256 && (long long)k_cols * Z <= 4096 && n_steps > 0) {
