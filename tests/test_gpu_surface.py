@@ -253,3 +253,40 @@ def test_error_counters_on_device():
     # and the batch agrees with the CPU oracle bit for bit
     eh, ei, ec, _ = bp_oracle.c_decode(code, cfg, batch.llr.cpu().numpy().astype(np.float64))
     assert np.array_equal(eh, hard) and np.array_equal(ei, iters) and np.array_equal(ec, conv)
+
+
+def test_error_counters_word_lengths_strides_and_byte_values():
+    """ldpc_count_errors on random bytes: word lengths that are and are not multiples of four, lengths past one
+    four-load round of a wave (1 024 positions), rows shifted off word alignment, one reference word for all
+    frames (stride 0), and byte values other than 0 / 1 (the float check of ldpc.py:158 marks a position 2) -
+    a position counts when its bytes differ."""
+    import torch
+    from ldpc_amd import _lib
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(12)
+    lib = _lib.load()
+    for n, frames, shift, stride0 in ((512, 300, 0, False), (2080, 77, 0, False), (26112, 9, 0, False), (1021, 50, 0, False),
+                                      (648, 120, 1, False), (1300, 31, 0, True), (4, 5, 0, False), (1028, 3, 2, True)):
+        hard = rng.integers(0, 3, size=(frames, n), dtype=np.uint8)
+        hard[:, ::7] = 255
+        ref = hard.copy()
+        flip = rng.random((frames, n)) < 0.03
+        ref[flip] ^= rng.integers(1, 256, size=int(flip.sum()), dtype=np.uint8)
+        ref[::3] = hard[::3]                                    # a third of the frames without errors
+        if stride0:
+            ref = np.repeat(ref[:1], frames, axis=0)
+        conv = rng.integers(0, 2, size=frames, dtype=np.uint8)
+        iters = rng.integers(0, 30, size=frames, dtype=np.int32)
+        flat_h = torch.zeros(frames * n + 8, dtype=torch.uint8, device=dev)
+        flat_r = torch.zeros(frames * n + 8, dtype=torch.uint8, device=dev)
+        flat_h[shift:shift + frames * n] = torch.as_tensor(hard.reshape(-1), device=dev)
+        flat_r[shift:shift + frames * n] = torch.as_tensor(ref.reshape(-1), device=dev)
+        ctr = torch.zeros((5,), dtype=torch.int64, device=dev)
+        ti, tc = torch.as_tensor(iters, device=dev), torch.as_tensor(conv, device=dev)
+        _lib.check(lib.ldpc_count_errors(flat_h.data_ptr() + shift, flat_r.data_ptr() + shift, 0 if stride0 else n, ti.data_ptr(),
+                                         tc.data_ptr(), frames, n, ctr.data_ptr(), None))
+        torch.cuda.synchronize()
+        errs = (hard != ref).sum(axis=1)
+        c = conv.astype(bool)
+        want = [frames, int((~c).sum()), int((c & (errs > 0)).sum()), int(errs.sum()), int(iters.sum())]
+        assert ctr.cpu().tolist() == want, (n, frames, shift, stride0)
