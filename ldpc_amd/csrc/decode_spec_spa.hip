@@ -15,7 +15,10 @@
 // R3  channel.py:402-513  tanh rule, 0.85 * 2 * atanh, product clip 0.99999999, posterior clip 50
 // R4  channel.py:260-398  phi rule, sum clip [1e-12, 20], posterior clip 500
 // The clips arrive in the configuration; prefix products and suffix products replace the
-// reference's per-target loops (agreement to rounding, see the table-driven kernel).
+// reference's per-target loops (agreement to rounding, see the table-driven kernel).  The tanh rules
+// (R2, R3) evaluate a whole check at once through spa_check_tanh (spec_common.h): numerators and
+// denominators of the tanh values are multiplied separately and one logarithm of a quotient replaces
+// tanh followed by atanh.
 //
 // FUSED: the channel in front and the error accounting behind run inside the kernel (sweep_fused.h),
 // as in the single-wave min-sum kernels of decode_spec.hip: the lanes draw the LLRs of the group's
@@ -146,15 +149,9 @@ spec_spa_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t 
                         else *reinterpret_cast<T *>(msg_b + LY::row(e0 + p) * Z * ST + zb) = m;
                     };
                     if constexpr (RULE == 2 || RULE == 3) {  // bpsk.py:325-339, channel.py:471-474
-                        T th[D > 0 ? D : 1], suf[D > 0 ? D : 1];
-                        static_for<0, D>([&](auto p) { th[p] = spa_tanh_half(v[p], g.clip_tanh_arg); });
-                        T run = (T)1;
-                        static_for<0, D>([&](auto pp) { constexpr int p = D - 1 - pp; suf[p] = run; run *= th[p]; });
-                        T pre = (T)1;
-                        static_for<0, D>([&](auto p) {
-                            put(p, spa_message(pre * suf[p], g.clip_prod, g.scale, RULE == 3));
-                            pre *= th[p];
-                        });
+                        T o[D > 0 ? D : 1];
+                        spa_check_tanh<T, D>(v, o, g.clip_tanh_arg, g.clip_prod, g.scale, RULE == 3);
+                        static_for<0, D>([&](auto p) { put(p, o[p]); });
                     } else {  // channel.py:332-352
                         T ph[D > 0 ? D : 1], suf[D > 0 ? D : 1];
                         unsigned neg = 0;

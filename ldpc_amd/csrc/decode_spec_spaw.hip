@@ -147,16 +147,9 @@ spec_spaw_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, uint8_t
                                 T v[D > 0 ? D : 1];
                                 static_for<0, D>([&](auto p) { v[p] = *reinterpret_cast<const T *>(msg_b + (e0 + p) * Z * ST + zb); });
                                 if constexpr (RULE == 2 || RULE == 3) {  // bpsk.py:325-339, channel.py:471-474
-                                    T th[D > 0 ? D : 1], suf[D > 0 ? D : 1];
-                                    static_for<0, D>([&](auto p) { th[p] = spa_tanh_half(v[p], g.clip_tanh_arg); });
-                                    T run = (T)1;
-                                    static_for<0, D>([&](auto pp) { constexpr int p = D - 1 - pp; suf[p] = run; run *= th[p]; });
-                                    T pre = (T)1;
-                                    static_for<0, D>([&](auto p) {
-                                        *reinterpret_cast<T *>(msg_b + (e0 + p) * Z * ST + zb) =
-                                            spa_message(pre * suf[p], g.clip_prod, g.scale, RULE == 3);
-                                        pre *= th[p];
-                                    });
+                                    T o[D > 0 ? D : 1];
+                                    spa_check_tanh<T, D>(v, o, g.clip_tanh_arg, g.clip_prod, g.scale, RULE == 3);
+                                    static_for<0, D>([&](auto p) { *reinterpret_cast<T *>(msg_b + (e0 + p) * Z * ST + zb) = o[p]; });
                                 } else {  // channel.py:332-352
                                     T ph[D > 0 ? D : 1], suf[D > 0 ? D : 1];
                                     unsigned neg = 0;
@@ -380,16 +373,9 @@ spec_spaw_slots_kernel(Cfg<T> g, const TL *__restrict__ llr, long long frames, u
                             T v[D > 0 ? D : 1];
                             static_for<0, D>([&](auto p) { v[p] = *reinterpret_cast<const T *>(msg_b + (e0 + p) * Z * ST + zb); });
                             if constexpr (RULE == 2 || RULE == 3) {  // bpsk.py:325-339, channel.py:471-474
-                                T th[D > 0 ? D : 1], suf[D > 0 ? D : 1];
-                                static_for<0, D>([&](auto p) { th[p] = spa_tanh_half(v[p], g.clip_tanh_arg); });
-                                T run = (T)1;
-                                static_for<0, D>([&](auto pp) { constexpr int p = D - 1 - pp; suf[p] = run; run *= th[p]; });
-                                T pre = (T)1;
-                                static_for<0, D>([&](auto p) {
-                                    *reinterpret_cast<T *>(msg_b + (e0 + p) * Z * ST + zb) =
-                                        spa_message(pre * suf[p], g.clip_prod, g.scale, RULE == 3);
-                                    pre *= th[p];
-                                });
+                                T o[D > 0 ? D : 1];
+                                spa_check_tanh<T, D>(v, o, g.clip_tanh_arg, g.clip_prod, g.scale, RULE == 3);
+                                static_for<0, D>([&](auto p) { *reinterpret_cast<T *>(msg_b + (e0 + p) * Z * ST + zb) = o[p]; });
                             } else {  // channel.py:332-352
                                 T ph[D > 0 ? D : 1], suf[D > 0 ? D : 1];
                                 unsigned neg = 0;

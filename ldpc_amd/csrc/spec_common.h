@@ -270,4 +270,53 @@ __device__ __forceinline__ bool r1_slot_ok(const unsigned long long (&hm)[C::NB]
 }
 
 
+// Check node of the tanh rules R2 / R3 for all D inputs of a check at once (bpsk.py:325-339, channel.py:471-474):
+//     out_p = c * 2 atanh(clip(prod over j != p of tanh(clip(v_j / 2)))),   c = 1 (R2) or the scale (R3).
+// With e_j = exp(-|v_j|): tanh(|v_j| / 2) = (1 - e_j) / (1 + e_j) = a_j / b_j, and for N = prod a_j, M = prod b_j
+// over the other inputs 2 atanh(N / M) = log((M + N) / (M - N)): one exponential, one division and one logarithm
+// per edge where tanh and atanh evaluated one after the other take an exponential, a logarithm, two divisions and
+// two small-argument series.  The inner clip |v_j / 2| <= c is |v_j| <= 2 c, the product clip N / M <= lim is
+// N <= lim * M.  Signs travel apart as sign bits; a zero input makes N = 0 and the message +-0, as tanh(0) = 0
+// does in the reference.  Against the reference's own evaluation the results differ by rounding only (1 - e_j
+// carries an absolute error of one ulp of 1, so messages near zero are exact to that, not to their own ulp).
+template <typename T, int D, int NV>
+__device__ __forceinline__ void spa_check_tanh(const T (&v)[NV], T (&out)[NV], T clip_arg, T clip_prod, T scale, bool scaled)
+{
+    if constexpr (D > 0) {
+        T a[D], b[D], sa[D], sb[D];
+        unsigned sx = 0;
+        const T lim = clip_prod < Lim<T>::below_one() ? clip_prod : Lim<T>::below_one();
+        static_for<0, D>([&](auto p) {
+            T m = t_abs(v[p]);
+            if (clip_arg > (T)0) m = m < (T)2 * clip_arg ? m : (T)2 * clip_arg;
+            const T e = f_exp(-m);
+            a[p] = (T)1 - e;
+            b[p] = (T)1 + e;
+            sx ^= SNum<T>::sign_word(v[p]);
+        });
+        T ra = (T)1, rb = (T)1;
+        static_for<0, D>([&](auto pp) {
+            constexpr int p = D - 1 - pp;
+            sa[p] = ra; sb[p] = rb;
+            ra *= a[p]; rb *= b[p];
+        });
+        T pa = (T)1, pb = (T)1;
+        T k;  // float: the logarithm comes to base two, its factor log(2) joins the scale
+        if constexpr (sizeof(T) == 4) k = scaled ? scale * 0.693147181f : 0.693147181f;
+        else k = scale;
+        static_for<0, D>([&](auto p) {
+            T n = pa * sa[p];
+            const T m = pb * sb[p];
+            pa *= a[p]; pb *= b[p];
+            const T cap = lim * m;
+            n = n < cap ? n : cap;
+            const T r = f_div(m + n, m - n);
+            T mag;
+            if constexpr (sizeof(T) == 4) mag = k * __builtin_amdgcn_logf(r);
+            else { mag = f_log(r); if (scaled) mag = k * mag; }
+            out[p] = SNum<T>::with_sign(mag, sx ^ SNum<T>::sign_word(v[p]));
+        });
+    }
+}
+
 }  // namespace ldpc
