@@ -137,3 +137,40 @@ def test_random_messages_on_the_device(name):
         for k in ("frames", "not_converged", "bit_errors", "iterations"):
             assert one[0][k] == two[0][k] + two[1][k]
         assert 0 < one[0]["not_converged"] < 50_000
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bg,Z", [(1, 8), (1, 12), (1, 20), (1, 36), (1, 96), (1, 104), (1, 208), (1, 320), (2, 8), (2, 28), (2, 64),
+                                  (2, 384), (1, 6), (1, 9), (2, 15)])
+def test_device_encoder_over_lifting_sizes(bg, Z):
+    """Both base graphs at lifting sizes that are multiples of four (the word-wide kernel: sizes below one wave,
+    sizes that are not multiples of eight or of 64, several frames per workgroup) and sizes that are not (the
+    byte-wide kernel): device encoder == host schedule, every word a codeword, ragged frame counts."""
+    import torch
+    from ldpc_amd import nr_rate_match as rm
+    dev = torch.device("cuda", 0)
+    base = codes.load_packaged("nr_bg1_z384" if bg == 1 else "nr_bg2_z40").qc
+    code = codes.compile_qc(rm.lift(base, Z), f"bg{bg}_z{Z}")
+    s = encoder.schedule_for(code, None)
+    assert s is not None
+    enc = encoder.DeviceEncoder(s)
+    rng = np.random.default_rng(Z)
+    for frames in (1, 3, 257):
+        msgs = rng.integers(0, 2, size=(frames, s.k), dtype=np.uint8)
+        msgs[0, :] = 1
+        cw = enc(torch.as_tensor(msgs, device=dev)).cpu().numpy()
+        assert np.array_equal(cw, s.run_host(msgs)), (bg, Z, frames)
+        assert all(code.is_codeword(c) for c in cw[:5])
+    # messages drawn on the device: the same stream whatever kernel serves the size, and msg_out is the message
+    cw, msg = enc.random_codewords(41, [3, Z], first_frame=2, device=dev, want_messages=True)
+    assert np.array_equal(cw.cpu().numpy(), s.run_host(msg.cpu().numpy()))
+    # message bytes with upper bits set count by their low bit; rows off word alignment take the byte-wide kernel
+    raw = rng.integers(0, 256, size=(9, s.k), dtype=np.uint8)
+    cw = enc(torch.as_tensor(raw, device=dev)).cpu().numpy()
+    assert np.array_equal(cw, s.run_host(raw & 1))
+    flat = torch.zeros(9 * s.k + 4, dtype=torch.uint8, device=dev)
+    flat[1:1 + 9 * s.k] = torch.as_tensor(raw.reshape(-1), device=dev)
+    out = torch.empty((9, s.n), dtype=torch.uint8, device=dev)
+    enc.encode_ptr(flat.data_ptr() + 1, 9, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), cw)
