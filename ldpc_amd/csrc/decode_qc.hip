@@ -25,6 +25,7 @@
 
 #include "bp_common.h"
 #include "bp_math.h"
+#include "spec_common.h"  // spa_check_tanh
 
 namespace ldpc {
 
@@ -122,18 +123,10 @@ __device__ __forceinline__ int check_row(const QcCtx &x, const Cfg<T> &g, const_
             msg[e0 * x.FZ + x.tid] = (T)0;
         }
     } else if (RULE == 2 || RULE == 3) {
-        T th[D], suf[D];
+        T o[D];  // the whole check at once: see spa_check_tanh (spec_common.h)
+        spa_check_tanh<T, D>(v, o, g.clip_tanh_arg, g.clip_prod, g.scale, RULE == 3);
 #pragma unroll
-        for (int p = 0; p < D; ++p) th[p] = spa_tanh_half(v[p], g.clip_tanh_arg);
-        T run = (T)1;
-#pragma unroll
-        for (int p = D - 1; p >= 0; --p) { suf[p] = run; run *= th[p]; }
-        T pre = (T)1;
-#pragma unroll
-        for (int p = 0; p < D; ++p) {
-            msg[(e0 + p) * x.FZ + x.tid] = spa_message(pre * suf[p], g.clip_prod, g.scale, RULE == 3);
-            pre *= th[p];
-        }
+        for (int p = 0; p < D; ++p) msg[(e0 + p) * x.FZ + x.tid] = o[p];
     } else {
         T ph[D], suf[D];
         unsigned neg = 0;
