@@ -289,6 +289,9 @@ __device__ __forceinline__ void spa_check_tanh(const T (&v)[NV], T (&out)[NV], T
         static_for<0, D>([&](auto p) {
             T m = t_abs(v[p]);
             if (clip_arg > (T)0) m = m < (T)2 * clip_arg ? m : (T)2 * clip_arg;
+            // saturated, infinite or NaN inputs: e^-700 is far below an ulp of 1 already, and the range reduction of the
+            // double-precision exponential is built for finite arguments (the hardware exp2 of the float path is not)
+            if constexpr (sizeof(T) == 8) m = m < (T)700 ? m : (T)700;
             const T e = f_exp(-m);
             a[p] = (T)1 - e;
             b[p] = (T)1 + e;

@@ -99,3 +99,41 @@ def test_tiny_liftings_put_many_frames_in_a_workgroup(Z, c_oracle):
             assert np.array_equal(res.iters, want[1]) and np.array_equal(res.converged, want[2])
             assert np.array_equal(res.hard, want[0]) and np.array_equal(np.asarray(res.posterior, np.float64), want[3]), res.kernel
     assert want[2].sum() > 0
+
+
+@pytest.mark.parametrize("name,snr", [("ccsds512", 0.0), ("wifi648", 0.0), ("nr_bg2_z40", -5.0)])
+@pytest.mark.parametrize("rule", ["R2", "R3"])
+def test_saturated_and_infinite_llrs_tanh_rules(name, snr, rule, c_oracle):
+    """Channel values of +-1e30, +-infinity and +-1e4 (known or filler positions, saturated front ends) under the
+    tanh rules: numpy's tanh saturates at +-1 and the product clip takes over (bpsk.py:333-339, channel.py:471-474);
+    every kernel family gives the C restatement's decisions, iteration counts and (finite) posteriors."""
+    from ldpc_amd.decoder import Decoder
+    code = codes.load_packaged(name)
+    dec = Decoder(code)
+    cfg = config.PRESETS[rule].with_(max_iters=10)
+    rng = np.random.default_rng(17)
+    s2 = 1 / (2 * 10 ** (snr / 10))
+    sign = -1.0 if cfg.plus_is_bit else 1.0
+    frames = 48
+    L = (2 * (sign + np.sqrt(s2) * rng.standard_normal((frames, code.n))) / s2).astype(np.float32).astype(np.float64)
+    for value, share in ((1e30, 0.02), (np.inf, 0.02), (1e4, 0.03)):
+        pick = rng.random(L.shape) < share
+        L[pick] = sign * value                     # known bits of the all-zero word
+    wrong = rng.random(L.shape) < 0.002
+    L[wrong] = -sign * 1e30                        # and a few saturated the wrong way
+    L[0, :] = sign * np.inf
+    L[1, : code.n // 2] = sign * 1e30
+    want = c_oracle.c_decode(code, cfg, L)
+    assert not np.isnan(want[3]).any() and 0 < want[2].sum()   # (a frame that passes the first test keeps its infinite LLRs as posteriors)
+    for kernel in (_lib.KERNEL_AUTO, _lib.KERNEL_QC, _lib.KERNEL_CSR):
+        res = dec.decode(L, cfg, compute_dtype=np.float64, want_posterior=True, kernel=kernel)
+        assert np.array_equal(res.iters, want[1]) and np.array_equal(res.converged, want[2]), res.kernel
+        assert np.array_equal(res.hard, want[0]), res.kernel
+        assert not np.isnan(res.posterior).any() and np.allclose(res.posterior, want[3], rtol=1e-4, atol=1e-9), res.kernel
+    res = dec.decode(L.astype(np.float32), cfg, compute_dtype=np.float32, want_posterior=True)
+    assert not np.isnan(res.posterior).any()
+    # float arithmetic saturates the product clip one float ulp below 1 (messages up to 17 instead of 21): frames
+    # at the edge may end differently, frames both arithmetic types decode end in the same word
+    both = res.converged.astype(bool) & want[2].astype(bool)
+    assert both[0]   # the all-infinite frame; the wrong-way saturations fail most of the others in either arithmetic
+    assert np.array_equal(res.hard[both], want[0][both])
