@@ -95,8 +95,9 @@ encode_qc_kernel(EncDev e, const uint8_t *__restrict__ msg, long long frames, ui
 // Only the columns that some term reads live in LDS (5G NR base graph 1: 26 of 68 - the 42 extension
 // parity columns are written once and never read); every column goes to the codeword as it is produced.
 // The schedule arrives as separate read-only pointers: their words are the same for every lane and come
-// by scalar loads, four terms of a step in one load (the steps' term lists are padded to multiples of four
-// with terms that read an all-zero slot), so that four LDS reads are in flight together.
+// by scalar loads, four terms of a step at a time and already decoded (word-aligned shift, byte offset of the
+// source slot, byte shift; the steps' term lists are padded to multiples of four with terms that read an
+// all-zero slot), so that four LDS reads are in flight together and the scalar unit only loads.
 __global__ void __launch_bounds__(1024)
 encode_qc4_kernel(int Z, int n_slots, int nb, int k_cols, int n_steps, const int *__restrict__ info_cols,
                   const int *__restrict__ info_slot, const int *__restrict__ step_out, const int *__restrict__ step_slot,
@@ -158,19 +159,21 @@ encode_qc4_kernel(int Z, int n_slots, int nb, int k_cols, int n_steps, const int
             const int t1 = step_ptr4[s + 1];
             unsigned acc = 0;
             for (int t = step_ptr4[s]; t < t1; t += 4) {
-                const uint4 tm = *reinterpret_cast<const uint4 *>(terms4 + t);
-                const unsigned term[4] = {tm.x, tm.y, tm.z, tm.w};
+                const unsigned *grp4 = terms4 + 3 * t;  // the group's twelve words, decoded on the host
+                const uint4 sh = *reinterpret_cast<const uint4 *>(grp4), at = *reinterpret_cast<const uint4 *>(grp4 + 4),
+                            bs = *reinterpret_cast<const uint4 *>(grp4 + 8);
+                const unsigned s4[4] = {sh.x, sh.y, sh.z, sh.w}, base[4] = {at.x, at.y, at.z, at.w}, by[4] = {bs.x, bs.y, bs.z, bs.w};
                 unsigned lo[4], hi[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    unsigned o = q4 + (term[u] & 0xfffcu);  // aligned offset of the word that holds position (4 q + s) mod Z
+                    unsigned o = q4 + s4[u];  // aligned offset of the word that holds position (4 q + s) mod Z
                     o = o >= (unsigned)Z ? o - (unsigned)Z : o;
-                    const unsigned char *src = xs + (term[u] >> 16) * CS + o;
+                    const unsigned char *src = xs + base[u] + o;
                     lo[u] = *reinterpret_cast<const unsigned *>(src);
                     hi[u] = *reinterpret_cast<const unsigned *>(src + 4);
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) acc ^= __builtin_amdgcn_alignbyte(hi[u], lo[u], term[u] & 3u);
+                for (int u = 0; u < 4; ++u) acc ^= __builtin_amdgcn_alignbyte(hi[u], lo[u], by[u]);
             }
             put(step_slot[s], acc);
             const int c = step_out[s];

@@ -28,7 +28,7 @@ struct EncDev {
     const int *info_slot4;    // [k_cols] slot of an information column, -1 = nothing reads it
     const int *step_slot4;    // [n_steps] slot of a step's output, -1 = nothing reads it
     const int *step_ptr4;     // [n_steps + 1], multiples of four
-    const unsigned *terms4;   // slot << 16 | shift; 16-byte aligned
+    const unsigned *terms4;   // per group of four terms twelve words: shifts & ~3, byte offsets of the slots, shifts & 3; 16-byte aligned
 };
 hipError_t launch_encode_qc(const EncDev &e, const uint8_t *msg, long long frames, uint8_t *cw, int num_cus,
                             hipStream_t stream, bool *supported, unsigned long long seed, unsigned long long first_frame,

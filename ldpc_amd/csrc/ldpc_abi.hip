@@ -11,6 +11,7 @@
 #include <dlfcn.h>
 
 #include <memory>
+#include <array>
 #include <vector>
 
 #include "bp_common.h"
@@ -689,16 +690,21 @@ extern "C" int32_t ldpc_encoder_create(int32_t Z, int32_t n_cols, int32_t nb, in
         sslot_at = host.size();
         for (int s = 0; s < n_steps; ++s) host.push_back(slot[step_out[s]]);
         ptr4_at = host.size();
-        std::vector<int> padded;
+        // terms in groups of four, decoded for the kernel: per group twelve words - the four word-aligned shifts,
+        // the four byte offsets of the source slots (a slot is Z + 4 bytes), the four byte shifts
+        std::vector<std::array<int, 3>> padded;
         for (int s = 0; s < n_steps; ++s) {
             host.push_back((int)padded.size());
-            for (int t = step_ptr[s]; t < step_ptr[s + 1]; ++t) padded.push_back((int)(((unsigned)slot[term_col[t]] << 16) | (unsigned)term_shift[t]));
-            while (padded.size() % 4) padded.push_back((int)((unsigned)n_slots << 16));
+            for (int t = step_ptr[s]; t < step_ptr[s + 1]; ++t)
+                padded.push_back({term_shift[t] & ~3, slot[term_col[t]] * (Z + 4), term_shift[t] & 3});
+            while (padded.size() % 4) padded.push_back({0, n_slots * (Z + 4), 0});
         }
         host.push_back((int)padded.size());
         while (host.size() % 4) host.push_back(0);
         terms4_at = host.size();
-        host.insert(host.end(), padded.begin(), padded.end());
+        for (size_t g = 0; g < padded.size(); g += 4)
+            for (int w = 0; w < 3; ++w)
+                for (int u = 0; u < 4; ++u) host.push_back(padded[g + u][w]);
     }
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&enc->d_ints), host.size() * sizeof(int) + 16));
     hipError_t e = hipMemcpy(enc->d_ints, host.data(), host.size() * sizeof(int), hipMemcpyHostToDevice);
