@@ -204,11 +204,13 @@ def test_pack_bits_ragged_word_length():
     import torch
     dev = torch.device("cuda", 0)
     rng = np.random.default_rng(3)
-    for frames, n in ((1, 1), (5, 13), (300, 1001)):
-        raw = rng.integers(0, 256, size=(frames, n + 3), dtype=np.uint8)      # rows 3 bytes apart from dense
+    # rows 3 bytes apart from dense (a byte at a time), and rows a multiple of eight bytes apart (eight positions per load,
+    # the last byte of a ragged word a byte at a time)
+    for frames, n, stride in ((1, 1, 4), (5, 13, 16), (300, 1001, 1004), (7, 1001, 1008), (64, 520, 520), (3, 8, 8), (9, 2077, 2080)):
+        raw = rng.integers(0, 256, size=(frames, stride), dtype=np.uint8)
         src = torch.as_tensor(raw, device=dev)
         out = torch.full((frames, (n + 7) // 8 + 2), 0xAA, dtype=torch.uint8, device=dev)
-        _lib.check(_lib.load().ldpc_pack_bits(src.data_ptr(), n + 3, frames, n, out.data_ptr(), out.shape[1],
+        _lib.check(_lib.load().ldpc_pack_bits(src.data_ptr(), stride, frames, n, out.data_ptr(), out.shape[1],
                                               torch.cuda.current_stream().cuda_stream or None))
         torch.cuda.synchronize()
         got = out.cpu().numpy()
