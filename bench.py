@@ -448,7 +448,7 @@ def other_workloads(head, args, torch, dist, device, world, rank):
     ]:
         run(label, head, rule, dtype, snr, early, frames if rule != "R3" else frames // 4)
     run("R3_f64_fixed_10", head, "R3", "f64", 1.0, False, frames // 8)
-    # BASELINE configuration 1: the small code of Matrices/H.txt (802.11n (648,324)), 65 536 frames, min-sum
+    # the small code of Matrices/H.txt (802.11n (648,324)), 65 536 frames, min-sum
     wifi = Runner("wifi648", torch, dist, device, world, rank)
     run("WIFI648_R1_f64_fixed_10", wifi, "R1", "f64", 1.0, False, 65536)
     run("WIFI648_R1_f32_fixed_10", wifi, "R1", "f32", 1.0, False, 65536)
@@ -474,10 +474,10 @@ def other_workloads(head, args, torch, dist, device, world, rank):
 def link_workloads(head, bg2, args, torch, dist, device, world, rank):
     """The steps around the decoder: the Monte-Carlo loop body as one launch (ldpc_sweep_batch) beside
     the same work as three launches, the mixed CCSDS + 5G sum-product batch under the Doppler-shifted
-    channel (BASELINE configuration 5), the device encoder and 5G rate recovery."""
+    channel, the device encoder and 5G rate recovery."""
     from ldpc_amd import channel, config, encoder, nr_rate_match, sweep
     res = {}
-    cfo5 = channel.doppler_cfo(4000.0, compensated=0.999)   # the carrier offset of configuration 5
+    cfo5 = channel.doppler_cfo(4000.0, compensated=0.999)   # the carrier offset of the mixed CCSDS + 5G workload below
     for label, rn, rule, dtype, snr, frames, chan in (
             ("sweep_R0_f64_es_n0_1dB", head, "R0", np.float64, 1.0, min(args.frames, 1 << 19), {}),
             ("sweep_R1_f32_es_n0_1dB", head, "R1", np.float32, 1.0, min(args.frames, 1 << 19), {}),
@@ -485,7 +485,7 @@ def link_workloads(head, bg2, args, torch, dist, device, world, rank):
             # the large codes stage their LLRs in a scratch slice per workgroup: the fused launch saves the LLR
             # array and its HBM traffic, not time - channel and decode are bound by vector issue alike
             ("sweep_BG2_Z40_R1_f64_es_n0_-4dB", bg2, "R1", np.float64, -4.0, 32768, {}),
-            # the two halves of configuration 5 as whole Monte-Carlo steps: sum-product rule R3 under the Doppler-shifted channel
+            # the two halves of the mixed CCSDS + 5G workload as whole Monte-Carlo steps: sum-product rule R3 under the Doppler-shifted channel
             ("sweep_R3_f32_doppler_es_n0_1dB", head, "R3", np.float32, 1.0, min(args.frames, 1 << 18), {"cfo": cfo5}),
             ("sweep_BG2_Z40_R3_f32_doppler_es_n0_-4dB", bg2, "R3", np.float32, -4.0, 16384, {"cfo": cfo5})):
         code, dec = rn.code, rn.dec
@@ -507,7 +507,7 @@ def link_workloads(head, bg2, args, torch, dist, device, world, rank):
                       "frames": frames, "code": code.name, "rule": rule, "es_n0_db": snr, "early_exit": True,
                       "hbm_bytes_per_frame_fused": code.n, "hbm_bytes_per_frame_three_launches": 11 * code.n + 10}
         del cw
-    # configuration 5: CCSDS and 5G frames of one link in one call, sum-product rule R3, Doppler-shifted BPSK
+    # mixed workload: CCSDS and 5G frames of one link in one call, sum-product rule R3, Doppler-shifted BPSK
     cfg = config.R3.with_(max_iters=args.max_iters)
     cfo = cfo5
     parts = []

@@ -63,7 +63,7 @@ SPA_CASES = [("ccsds512", "R2", -0.5, 20_001, "spa"), ("ccsds512", "R3", -0.5, 2
 def test_fused_sum_product_counters_equal_three_launches(name, rule, snr, frames, family):
     """Rules R2, R3, R4 (bpsk.py:263-387, channel.py:402-513, 260-398) with their posterior clips: one launch
     against three, both arithmetic types, early exit and fixed work, with and without a carrier offset
-    (the channel of BASELINE configuration 5)."""
+    (the channel of the mixed CCSDS + 5G sum-product workload)."""
     import torch
     from ldpc_amd import channel
     dev = torch.device("cuda", 0)

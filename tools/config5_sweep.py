@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Error-rate curves of BASELINE configuration 5 on one GPU: the sum-product rule R3 (channel.py:402-513) on
+"""Error-rate curves of the mixed CCSDS + 5G sum-product workload on one GPU: the sum-product rule R3 (channel.py:402-513) on
 the CCSDS code and on the reference's 5G matrix under the Doppler-shifted BPSK channel (carrier offset of
 plotDoppler.py:14-16 after 99.9 % compensation), every Monte-Carlo step one fused launch (channel + decode +
 counting), float32 beside float64 on the same codewords and noise.  Prints one JSON object.
